@@ -1,0 +1,239 @@
+"""Pins the CPU oracle (oracle/prw_oracle.c) against every golden the reference holds for the path.
+
+Each test names the reference test / notebook cell it mirrors
+(JAXI = routing_board_generation/board_generation_methods/jax_implementation/board_generation).
+"""
+import numpy as np
+import pytest
+
+WINDOW = [0, 1, 2, 7, 8, 9]          # numpy summarised print: 3 leading + 3 trailing items
+WINDOW_BOARDS = [0, 1, 2, 97, 98, 99]
+
+
+def _agents(d):
+    return {k: np.asarray(v, np.int32) for k, v in d.items()}
+
+
+# --------------------------------------------------------------------------- PRNG (G1, A.2)
+def test_prngkey_and_split_known_answer(oracle):
+    # State.key printed in profiling_generators.ipynb cells 4/7/10/13 == split(PRNGKey(0))[0]
+    ks = oracle.split(oracle.prng_key(0))
+    assert ks.tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    assert oracle.prng_key(7).tolist() == [0, 7]
+    assert oracle.prng_key((5 << 32) | 9).tolist() == [5, 9]
+
+
+def test_batch_keys_match_notebook(oracle, goldens):
+    # keys = jax.random.split(PRNGKey(0), 100) pass through generator: State.key = split(k)[0]
+    b = goldens["notebook"]["batch100_10x10_5_split_PRNGKey0"]["parallel_random_walk"]
+    keys = oracle.split(oracle.prng_key(0), 100)
+    got = np.stack([oracle.split(k)[0] for k in keys])
+    assert (got == np.asarray(b["key"], np.uint32)).all()
+
+
+def test_random_bits_odd_padding(oracle):
+    # threefry_2x32 pads an odd count with one 0 word: the first ceil(n/2) words use counters
+    # (j, half+j); the last block of an odd request uses (half-1, 0).
+    key = oracle.split(oracle.prng_key(3))[1]
+    bits5 = oracle.random_bits(key, 5)
+    for j in range(3):
+        c1 = 3 + j if 3 + j < 5 else 0
+        y0, y1 = oracle.threefry2x32(key, j, c1)
+        assert bits5[j] == y0
+        if 3 + j < 5:
+            assert bits5[3 + j] == y1
+    assert oracle.random_bits(key, 1)[0] == oracle.threefry2x32(key, 0, 0)[0]
+
+
+def test_uniform_range(oracle):
+    for s in range(50):
+        u = oracle.uniform(oracle.prng_key(s))
+        assert 0.0 <= float(u) < 1.0
+
+
+# --------------------------------------------------------------------------- reference unit tests
+def test_initialise_agents(oracle, goldens):  # JAXI/test_...py::test_initialise_agents
+    tf = goldens["test_file"]
+    grid, agents = oracle.initialise_agents(oracle.prng_key(0), 5, 3)
+    assert (grid == np.asarray(tf["valid_starting_grid"])).all()
+    exp = _agents(tf["agents_starting"])
+    for k in exp:
+        assert (agents[k] == exp[k]).all(), k
+
+
+def test_step(oracle, goldens):  # ::test_step
+    tf = goldens["test_file"]
+    key = oracle.prng_key(0)
+    new_key, grid, agents = oracle.prw_step(key, tf["valid_starting_grid"], tf["agents_starting"])
+    assert (new_key == oracle.split(key)[1]).all()
+    assert (grid == np.asarray(tf["valid_starting_grid_after_1_step"])).all()
+    exp = _agents(tf["agents_starting_move_1_step_up"])
+    for k in exp:
+        assert (agents[k] == exp[k]).all(), k
+
+
+def test_generate_board(oracle, goldens):  # ::test_generate_board
+    tf = goldens["test_file"]
+    heads, targets, grid, iters = oracle.generate_board(oracle.prng_key(0), 5, 3)
+    exp = _agents(tf["agents_reshaped_for_generator"])
+    assert (grid == np.asarray(tf["valid_end_grid2"])).all()
+    assert (heads.T == exp["start"]).all()
+    assert (targets.T == exp["position"]).all()
+    assert iters == 6
+
+
+def test_generate_board_for_various_keys(oracle):  # ::test_generate_board_for_various_keys
+    boards = [oracle.generate_board(oracle.prng_key(i), 5, 3)[2] for i in range(10)]
+    for i in range(10):
+        for j in range(i):
+            assert not (boards[i] == boards[j]).all()
+
+
+@pytest.mark.parametrize("grid_name,agents_name,expected",
+                         [("valid_end_grid", "agents_finished", False),
+                          ("valid_starting_grid", "agents_starting", True)])
+def test_continue_stepping(oracle, goldens, grid_name, agents_name, expected):
+    tf = goldens["test_file"]
+    assert oracle.continue_stepping(tf[grid_name], tf[agents_name]) == expected
+
+
+@pytest.mark.parametrize("cell,expected", [(0, [-1, 5, -1, 1]), (6, [1, 11, 5, 7])])
+def test_adjacent_cells(oracle, cell, expected):  # ::test_adjacent_cells
+    assert oracle.adjacent_cells(cell, 5, 5).tolist() == expected
+
+
+@pytest.mark.parametrize("grid_name,cell,expected",
+                         [("valid_end_grid", 8, [-1, -1, -1, -1]),
+                          ("grid_to_test_available_cells", 8, [-1, 13, -1, -1])])
+def test_available_cells(oracle, goldens, grid_name, cell, expected):  # ::test_available_cells
+    assert oracle.available_cells(goldens["test_file"][grid_name], cell).tolist() == expected
+
+
+@pytest.mark.parametrize("cell,expected", [(21, True), (22, False), (32, False)])
+def test_is_cell_free(oracle, goldens, cell, expected):  # ::test_is_cell_free
+    assert oracle.is_cell_free(goldens["test_file"]["valid_starting_grid"], cell) == expected
+
+
+@pytest.mark.parametrize("p1,p2,expected", [(0, 1, 2), (1, 0, 4), (0, 5, 3), (5, 0, 1)])
+def test_action_from_position(oracle, p1, p2, expected):  # ::test_action_from_position
+    assert oracle.action_from_positions(p1, p2, 5) == expected
+
+
+def test_action_from_position_sentinel(oracle):
+    # blocked agent -> choice returns -1 -> (-1, cols-1): NOOP except from (0, cols-1)
+    assert oracle.action_from_positions(7, -1, 5) == 0
+    assert oracle.action_from_positions(4, -1, 5) == 1  # UP, rejected later by is_valid_position
+
+
+def test_step_agent(oracle, goldens):  # ::test_step_agent, actions [1,1,1]
+    tf = goldens["test_file"]
+    exp_agents = _agents(tf["agents_starting_move_1_step_up"])
+    for i in range(3):
+        pos, grid = oracle.step_agent(i, tf["agents_starting"], tf["valid_starting_grid"], 1)
+        assert (grid == np.asarray(tf["grids_after_1_agent_step"][i])).all()
+        assert pos == exp_agents["position"][i].tolist()
+
+
+# --------------------------------------------------------------------------- notebook goldens
+@pytest.mark.parametrize("name", ["parallel_random_walk", "uniform"])
+def test_single_board_generators(oracle, goldens, name):  # profiling nb cells 4 and 13 (G5, G6)
+    s = goldens["notebook"]["single_10x10_5_PRNGKey0"][name]
+    st, _, iters = oracle.generate_batch(oracle.prng_key(0)[None], 10, 5, generator=name)
+    assert (st["grid"][0] == np.asarray(s["grid"])).all()
+    assert (st["start"][0] == np.asarray(s["start"])).all()
+    assert (st["target"][0] == np.asarray(s["target"])).all()
+    assert (st["position"][0] == np.asarray(s["position"])).all()
+    assert (st["key"][0] == np.asarray(s["key"], np.uint32)).all()
+    assert st["step_count"][0] == 0
+
+
+@pytest.mark.parametrize("name", ["parallel_random_walk", "uniform"])
+def test_batch100_generators(oracle, goldens, name):  # profiling nb cells 18 and 26
+    """vmap(generator)(split(PRNGKey(0), 100)): start/target/position/key are printed in full
+    (100x5x2 = 1000 elements, numpy's summarisation threshold), grids as 6x6x6 corner windows."""
+    b = goldens["notebook"]["batch100_10x10_5_split_PRNGKey0"][name]
+    keys = oracle.split(oracle.prng_key(0), 100)
+    st, _, _ = oracle.generate_batch(keys, 10, 5, generator=name, threads=2)
+    assert (st["start"] == np.asarray(b["start"])).all()
+    assert (st["target"] == np.asarray(b["target"])).all()
+    assert (st["position"] == np.asarray(b["position"])).all()
+    assert (st["key"] == np.asarray(b["key"], np.uint32)).all()
+    win = st["grid"][WINDOW_BOARDS][:, WINDOW][:, :, WINDOW]
+    assert (win == np.asarray(b["grid_window"])).all()
+
+
+# --------------------------------------------------------------------------- collision KAT
+def _kat_state():
+    grid = np.zeros((5, 5), np.int32)
+    grid[2, 0], grid[2, 1] = 1, 2       # agent 0: path + head
+    grid[2, 3] = 5                       # agent 1 head
+    grid[1, 2] = 8                       # agent 2 head
+    agents = {"id": [0, 1, 2], "start": [[2, 0], [2, 3], [1, 2]],
+              "target": [[-1, -1]] * 3, "position": [[2, 1], [2, 3], [1, 2]]}
+    return grid, agents
+
+
+def test_collision_kat_two_way(oracle):
+    """Hand-derived from JAXI/parallel_random_walk.py:104-107,128 (no reference golden has a
+    contested cell in a *single* pinned step; the 100-board batch golden covers it end-to-end)."""
+    grid, agents = _kat_state()
+    g, a = oracle.step_agents_with_actions(grid, agents, [2, 4, 0])  # RIGHT, LEFT, NOOP
+    assert g[2].tolist() == [1, 2, 5, 4, 0]
+    assert a["position"].tolist() == [[2, 1], [2, 2], [1, 2]]
+
+
+def test_collision_kat_three_way(oracle):
+    grid, agents = _kat_state()
+    g, a = oracle.step_agents_with_actions(grid, agents, [2, 4, 3])  # RIGHT, LEFT, DOWN
+    assert g[1].tolist() == [0, 0, 7, 0, 0]
+    assert g[2].tolist() == [1, 2, 8, 5, 0]
+    assert a["position"].tolist() == [[2, 1], [2, 3], [2, 2]]
+
+
+# --------------------------------------------------------------------------- structural invariants
+def _same_wire_neighbours(grid, r, c, wire):
+    m = grid.shape[0]
+    cnt = 0
+    for dr, dc in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+        rr, cc = r + dr, c + dc
+        if 0 <= rr < m and 0 <= cc < m and grid[rr, cc] != 0 and (grid[rr, cc] - 1) // 3 == wire:
+            cnt += 1
+    return cnt
+
+
+def check_solved_board(solved, start, target):
+    """verify_wire_validity (NPI/utils/post_processor_utils_numpy.py:90-121): head/target cells
+    have exactly one same-wire neighbour, path cells exactly two; a never-moved agent is a lone
+    TARGET cell."""
+    m = solved.shape[0]
+    N = start.shape[0]
+    for i in range(N):
+        sr, sc = start[i]
+        tr, tc = target[i]
+        assert solved[tr, tc] == 3 + 3 * i
+        if (sr, sc) == (tr, tc):
+            assert _same_wire_neighbours(solved, sr, sc, i) == 0
+        else:
+            assert solved[sr, sc] == 2 + 3 * i
+    for r in range(m):
+        for c in range(m):
+            v = solved[r, c]
+            if v == 0:
+                continue
+            wire, kind = (v - 1) // 3, (v - 1) % 3
+            n = _same_wire_neighbours(solved, r, c, wire)
+            if kind == 0:
+                assert n == 2, (r, c, v)
+            elif not (start[wire] == target[wire]).all():
+                assert n == 1, (r, c, v)
+
+
+def test_validity_invariants_c1_and_c2_shapes(oracle):
+    for (m, N, B) in ((8, 5, 64), (16, 10, 64)):
+        keys = oracle.split(oracle.prng_key(0), B)
+        st, solved, iters = oracle.generate_batch(keys, m, N, threads=2)
+        assert (iters > 0).all()
+        for b in range(B):
+            check_solved_board(solved[b], st["start"][b], st["target"][b])
+            # training grid holds heads+targets only
+            assert (st["grid"][b] != 0).sum() == 2 * N - (st["start"][b] == st["target"][b]).all(1).sum()
