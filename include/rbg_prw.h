@@ -1,0 +1,144 @@
+/*
+ * rbg_prw.h -- C-ABI of librbg_prw.so: the MI355X (gfx950) implementation of the reference's
+ * ParallelRandomWalk board generator and the coupled Jumanji Connector reset/step hot path.
+ *
+ * The reference is pure Python/JAX and has no FFI of its own; each entry point below names the
+ * reference interface it replaces (paths relative to the reference root;
+ * JAXI = routing_board_generation/board_generation_methods/jax_implementation/board_generation,
+ * [3P] = the un-vendored pip dependency that holds the behaviour, pinned in requirements.txt:4-5).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned HBM; nothing is allocated or freed here
+ *   - every call is asynchronous on the caller-supplied `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream); no hidden synchronisation, no global state, re-entrant,
+ *     capturable into a hipGraph
+ *   - arrays are dense, C-contiguous, batch-major:
+ *       keys        uint32 [B][2]          jax.random key data (Threefry-2x32)
+ *       grid        int32  [B][m][m]       0 empty, 1+3i path, 2+3i head/position, 3+3i target
+ *       start/target/position int32 [B][N][2]   (row, col) per agent
+ *       obs_grid    int32  [B][N][m][m]    per-agent view (_obs_from_grid)
+ *       action_mask uint8  [B][N][5]       NOOP, UP, RIGHT, DOWN, LEFT
+ *   - limits: 2 <= m <= 40 (one _shuffle round, as in jax for m*m <= 1625), 1 <= N <= 64,
+ *     N <= m*m (2N <= m*m for the uniform generator)
+ *   - return value: 0 ok; < 0 argument error (RBG_E_*); > 0 a hipError_t from the launch.
+ *     rbg_last_error() gives a thread-local message for the last non-zero return.
+ */
+#ifndef RBG_PRW_H_
+#define RBG_PRW_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBG_ABI_VERSION 1
+
+#define RBG_E_NULL (-1)   /* a required pointer is NULL */
+#define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
+#define RBG_E_PARAM (-3)  /* bad flag / parameter value */
+
+/* [3P] jumanji.environments.routing.connector.types.State (field order grid, step_count, agents,
+ * key as printed at package_evaluation/profiling_generators.ipynb cell 13); Agent.id is implicit
+ * (arange(N)). */
+typedef struct rbg_state {
+  int32_t *grid;       /* [B][m][m] */
+  int32_t *step_count; /* [B] */
+  int32_t *start;      /* [B][N][2] */
+  int32_t *target;     /* [B][N][2] */
+  int32_t *position;   /* [B][N][2] */
+  uint32_t *key;       /* [B][2] */
+} rbg_state;
+
+/* [3P] jumanji.types.TimeStep[Observation] + extras (keys confirmed by
+ * routing_board_generation/benchmarking/utils/benchmark_data_model.py:24-29).
+ * Any member may be NULL: that output is then skipped (e.g. obs_grid for a random policy). */
+typedef struct rbg_timestep {
+  int8_t *step_type;          /* [B]  0 FIRST, 1 MID, 2 LAST */
+  float *reward;              /* [B][N] */
+  float *discount;            /* [B][N] */
+  int32_t *obs_grid;          /* [B][N][m][m] */
+  uint8_t *action_mask;       /* [B][N][5] */
+  int32_t *obs_step_count;    /* [B] */
+  int32_t *num_connections;   /* [B] */
+  float *ratio_connections;   /* [B] */
+  int32_t *total_path_length; /* [B] */
+} rbg_timestep;
+
+/* [3P] Connector.__init__(time_limit=50) + DenseRewardFn(timestep_reward, connected_reward) +
+ * VmapAutoResetWrapper (auto_reset != 0 fuses its reset into the step). */
+typedef struct rbg_env_params {
+  int32_t time_limit;
+  float timestep_reward;
+  float connected_reward;
+  int32_t auto_reset;
+} rbg_env_params;
+
+int rbg_abi_version(void);
+const char *rbg_version(void);
+const char *rbg_last_error(void);
+
+/* ---- PRNG plumbing ([3P] jax.random.split, jax/_src/prng.py::threefry_split) -------------- */
+
+/* split(key, num) for ONE host-side key: out [num][2].
+ * Replaces `jax.random.split(jax.random.PRNGKey(0), batch_size)`
+ * (package_evaluation/profiling_generators.ipynb cell 16;
+ *  routing_board_generation/rl_training/setup_train.py:397). */
+int rbg_split(uint32_t key0, uint32_t key1, int num, uint32_t *out, void *stream);
+
+/* vmap(split)(keys, num): keys [B][2] -> out [B][num][2]. */
+int rbg_split_batch(const uint32_t *keys, int B, int num, uint32_t *out, void *stream);
+
+/* ---- board generation -------------------------------------------------------------------- */
+
+/* vmap(ParallelRandomWalkBoard(m, m, N).generate_board)(keys)          [split_first == 0]
+ *   JAXI/parallel_random_walk.py:60-90
+ * vmap(ParallelRandomWalkGenerator(m, N).__call__)(keys)               [split_first != 0]
+ *   routing_board_generation/rl_training/online_generators/parallel_random_walk_generator.py:46-77
+ *   (adds `key, _ = split(key)`; key_out = State.key)
+ * Outputs: solved_grid (nullable) = generate_board's 3rd result; train_grid (nullable) = the
+ * State.grid built at parallel_random_walk_generator.py:63-64 (heads and targets only);
+ * start = heads, target = final positions, both agent-major [B][N][2]; key_out (nullable);
+ * iters (nullable) = while_loop trip count per board. */
+int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
+                     int32_t *solved_grid, int32_t *train_grid, int32_t *start, int32_t *target,
+                     uint32_t *key_out, int32_t *iters, void *stream);
+
+/* vmap(UniformRandomGenerator(m, N).__call__)(keys)
+ *   routing_board_generation/rl_training/online_generators/uniform_generator.py:70-109 */
+int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *train_grid,
+                         int32_t *start, int32_t *target, uint32_t *key_out, void *stream);
+
+/* ---- Connector environment ([3P] jumanji/environments/routing/connector/env.py) ----------- */
+
+/* vmap(Connector(generator=ParallelRandomWalkGenerator(m, N)).reset)(keys)
+ *   call site: routing_board_generation/rl_training/setup_train.py:400 (pmap(env.reset)). */
+int rbg_connector_reset(const uint32_t *keys, int B, int m, int N, const rbg_state *state,
+                        const rbg_timestep *timestep, void *stream);
+
+/* Timestep for an existing state: vmap of _get_action_mask / _obs_from_grid / _get_extras +
+ * jumanji.types.restart, i.e. demos/board_generator_demo.py:80-96 (board_to_env) and
+ * package_evaluation/load_and_test_agents.ipynb:385-394. */
+int rbg_connector_observe(int B, int m, int N, const rbg_state *state,
+                          const rbg_timestep *timestep, void *stream);
+
+/* VmapAutoResetWrapper(Connector).step(state, action): state_in -> state_out (may alias).
+ *   call site: agent_training/training_script.py:70-79 via [3P] jumanji.training agents.
+ * action int32 [B][N] in 0..4.  With params->auto_reset, envs whose timestep is LAST are
+ * regenerated from split(state.key)[0] inside the same launch and only their observation is
+ * replaced ([3P] jumanji/wrappers.py::VmapAutoResetWrapper._auto_reset). */
+int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg_state *state_out,
+                       const int32_t *action, const rbg_env_params *params,
+                       const rbg_timestep *timestep, void *stream);
+
+/* Masked-uniform random policy over the legal set (defined by this project; stands in for
+ * [3P] jumanji.training.agents.random.RandomAgent in the rollout benchmark, BASELINE config 3):
+ * agent i of env b picks legal action number random_bits(fold_in(keys[b], t), N)[i] mod #legal. */
+int rbg_random_actions(const uint32_t *keys, int B, int N, uint32_t t, const uint8_t *action_mask,
+                       int32_t *action, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBG_PRW_H_ */

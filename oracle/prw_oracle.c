@@ -193,6 +193,7 @@ static inline int32_t floormod(int32_t a, int32_t b) { return a - floordiv(a, b)
 static void move_position(const int32_t pos[2], int action, int32_t out[2]) {
   static const int dr[5] = {0, -1, 0, 1, 0};
   static const int dc[5] = {0, 0, 1, 0, -1};
+  action = action < 0 ? 0 : action > 4 ? 4 : action; /* lax.switch clamps its index */
   out[0] = pos[0] + dr[action];
   out[1] = pos[1] + dc[action];
 }

@@ -1,0 +1,114 @@
+"""ctypes binding of librbg_prw.so (include/rbg_prw.h) -- the only compute path of this package.
+
+There is deliberately NO fallback: if the HIP library is missing or a launch fails, the call
+raises.  Build the library with `python __graft_entry__.py` (or `build_native()` below); the
+built .so lives in-tree under routing_board_generation_amd/lib/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
+SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
+HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
+
+ABI_VERSION = 1
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
+               "-std=c++17"]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class State(C.Structure):
+    _fields_ = [("grid", C.c_void_p), ("step_count", C.c_void_p), ("start", C.c_void_p),
+                ("target", C.c_void_p), ("position", C.c_void_p), ("key", C.c_void_p)]
+
+
+class Timestep(C.Structure):
+    _fields_ = [("step_type", C.c_void_p), ("reward", C.c_void_p), ("discount", C.c_void_p),
+                ("obs_grid", C.c_void_p), ("action_mask", C.c_void_p),
+                ("obs_step_count", C.c_void_p), ("num_connections", C.c_void_p),
+                ("ratio_connections", C.c_void_p), ("total_path_length", C.c_void_p)]
+
+
+class EnvParams(C.Structure):
+    _fields_ = [("time_limit", C.c_int32), ("timestep_reward", C.c_float),
+                ("connected_reward", C.c_float), ("auto_reset", C.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/rbg_prw.h one to one
+SIGNATURES = {
+    "rbg_abi_version": (C.c_int, []),
+    "rbg_version": (C.c_char_p, []),
+    "rbg_last_error": (C.c_char_p, []),
+    "rbg_split": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "rbg_split_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rbg_prw_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "rbg_uniform_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rbg_connector_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(State),
+                                      C.POINTER(Timestep), C.c_void_p]),
+    "rbg_connector_observe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
+                                        C.POINTER(Timestep), C.c_void_p]),
+    "rbg_connector_step": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
+                                     C.POINTER(State), C.c_void_p, C.POINTER(EnvParams),
+                                     C.POINTER(Timestep), C.c_void_p]),
+    "rbg_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+}
+
+
+def build_native(force: bool = False) -> str:
+    """Compile csrc/prw_kernels.hip for gfx950 into lib/librbg_prw.so (hipcc cross-compiles
+    without a GPU)."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    stale = (not os.path.exists(LIB_PATH)
+             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(SRC_PATH),
+                                                 os.path.getmtime(HEADER_PATH)))
+    if force or stale:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC_PATH]
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises NativeLibraryError when it is missing or of the wrong ABI."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                "(there is no CPU or PyTorch fallback for this path)")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.rbg_abi_version() != ABI_VERSION:
+            raise NativeLibraryError(
+                f"ABI mismatch: library {handle.rbg_abi_version()} != binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().rbg_last_error().decode()
+        kind = "argument error" if rc < 0 else f"hipError {rc}"
+        raise NativeLibraryError(f"{what} failed ({kind}): {msg}")

@@ -1,0 +1,161 @@
+"""Connector environment -- API of [3P] jumanji.environments.routing.connector.env.Connector
+(jumanji==0.2.2, pinned by the reference at requirements.txt:5), backed by `connector_kernel`.
+
+Call sites in the reference that this class serves:
+  routing_board_generation/rl_training/setup_train.py:158   Connector(generator=generator)
+  demos/board_generator_demo.py:83-96                       _get_action_mask/_obs_from_grid/_get_extras
+  package_evaluation/load_and_test_agents.ipynb:190-219     reset / step loop
+
+Every method accepts a single env (key (2,), State without batch axis) or a batch (key (B, 2),
+batched State): the batch form replaces `jax.vmap(env.reset)` / `jax.vmap(env.step)`.
+
+Semantics not pinned by any reference golden (reward constants, discount, termination,
+observation encoding, extras) are "defined by this project, modelled on jumanji 0.2.2";
+see DESIGN.md.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..online_generators.parallel_random_walk_generator import ParallelRandomWalkGenerator
+from ..online_generators.uniform_generator import Generator, UniformRandomGenerator
+from ..types import Agent, Observation, State, TimeStep
+
+
+class DenseRewardFn:
+    """[3P] connector/reward.py::DenseRewardFn: `connected_reward` on the step an agent connects,
+    `timestep_reward` on every step it starts unconnected."""
+
+    def __init__(self, timestep_reward: float = -0.03, connected_reward: float = 0.1) -> None:
+        self.timestep_reward = timestep_reward
+        self.connected_reward = connected_reward
+
+
+def _state_bufs(state: State, batched: bool):
+    def b(x):
+        return (x if batched else x[None]).contiguous()
+
+    return {"grid": b(state.grid), "step_count": b(state.step_count).reshape(-1),
+            "start": b(state.agents.start), "target": b(state.agents.target),
+            "position": b(state.agents.position), "key": b(state.key)}
+
+
+def _make_state(st, batched: bool) -> State:
+    B, N = st["start"].shape[0], st["start"].shape[1]
+    ids = torch.arange(N, dtype=torch.int32, device=st["start"].device).expand(B, N)
+    s = State(grid=st["grid"], step_count=st["step_count"],
+              agents=Agent(id=ids, start=st["start"], target=st["target"],
+                           position=st["position"]), key=st["key"])
+    if batched:
+        return s
+    return State(grid=s.grid[0], step_count=s.step_count[0],
+                 agents=Agent(*[x[0] for x in s.agents]), key=s.key[0])
+
+
+def _make_timestep(ts, batched: bool) -> TimeStep:
+    sel = (lambda x: x) if batched else (lambda x: x[0])
+    obs = Observation(grid=sel(ts["obs_grid"]) if "obs_grid" in ts else None,
+                      action_mask=sel(ts["action_mask"]), step_count=sel(ts["obs_step_count"]))
+    extras = {"num_connections": sel(ts["num_connections"]),
+              "ratio_connections": sel(ts["ratio_connections"]),
+              "total_path_length": sel(ts["total_path_length"])}
+    return TimeStep(step_type=sel(ts["step_type"]), reward=sel(ts["reward"]),
+                    discount=sel(ts["discount"]), observation=obs, extras=extras)
+
+
+class Connector:
+    def __init__(self, generator: Optional[Generator] = None, reward_fn: Optional[DenseRewardFn] = None,
+                 time_limit: int = 50, viewer=None) -> None:
+        self._generator = generator or UniformRandomGenerator(grid_size=10, num_agents=5)
+        self._reward_fn = reward_fn or DenseRewardFn()
+        self.time_limit = time_limit
+        self.num_agents = self._generator.num_agents
+        self.grid_size = self._generator.grid_size
+        self._viewer = viewer
+        self._auto_reset = False  # switched on by VmapAutoResetWrapper
+
+    @property
+    def unwrapped(self) -> "Connector":
+        return self
+
+    @property
+    def generator(self) -> Generator:
+        return self._generator
+
+    # ---------------------------------------------------------------------------------- reset
+    def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
+        batched = key.dim() == 2
+        keys = (key if batched else key[None]).contiguous()
+        if isinstance(self._generator, ParallelRandomWalkGenerator):
+            # fused: walk + State + observation in one launch
+            st, ts = ops.connector_reset(keys, self.grid_size, self.num_agents)
+        else:
+            st = _state_bufs(self._generator(keys), True)
+            ts = ops.connector_observe(st)
+        return _make_state(st, batched), _make_timestep(ts, batched)
+
+    # ---------------------------------------------------------------------------------- step
+    def step(self, state: State, action: torch.Tensor) -> Tuple[State, TimeStep]:
+        batched = state.grid.dim() == 3
+        st = _state_bufs(state, batched)
+        act = (action if batched else action[None]).to(torch.int32).contiguous()
+        fused_reset = self._auto_reset and isinstance(self._generator, ParallelRandomWalkGenerator)
+        so, ts = ops.connector_step(st, act, self.time_limit, self._reward_fn.timestep_reward,
+                                    self._reward_fn.connected_reward, auto_reset=fused_reset)
+        if self._auto_reset and not fused_reset:
+            so, ts = self._generic_auto_reset(so, ts)
+        return _make_state(so, batched), _make_timestep(ts, batched)
+
+    def _generic_auto_reset(self, so, ts):
+        """VmapAutoResetWrapper for generators without a fused kernel: regenerate every env from
+        split(state.key)[0] and select where the timestep is LAST (what vmap(lax.cond) does)."""
+        from ..random import split
+
+        done = ts["step_type"] == 2
+        new_keys = split(so["key"], 2)[:, 0].contiguous()
+        fresh = _state_bufs(self._generator(new_keys), True)
+        fresh_ts = ops.connector_observe(fresh)
+
+        def pick(new, old):
+            d = done.reshape((-1,) + (1,) * (old.dim() - 1))
+            return torch.where(d, new, old)
+
+        out = {}
+        for f in ("grid", "step_count", "start", "target", "position"):
+            out[f] = pick(fresh[f], so[f])
+        out["key"] = pick(fresh["key"].view(torch.int32), so["key"].view(torch.int32)).view(torch.uint32)
+        for f in ("obs_grid", "action_mask", "obs_step_count"):
+            ts[f] = pick(fresh_ts[f], ts[f])
+        return out, ts
+
+    # ------------------------------------------------- "private" methods the reference calls
+    def _timestep_of(self, state: State) -> TimeStep:
+        batched = state.grid.dim() == 3
+        return _make_timestep(ops.connector_observe(_state_bufs(state, batched)), batched)
+
+    def _get_action_mask(self, agents: Agent, grid: torch.Tensor) -> torch.Tensor:
+        """(N, 5) bool for all agents at once (the reference vmaps this over agents:
+        demos/board_generator_demo.py:85-87)."""
+        batched = grid.dim() == 3
+        B = grid.shape[0] if batched else 1
+        dev = grid.device
+        state = State(grid=grid, step_count=torch.zeros((B,) if batched else (), dtype=torch.int32, device=dev),
+                      agents=agents,
+                      key=torch.zeros((B, 2) if batched else (2,), dtype=torch.uint32, device=dev))
+        return self._timestep_of(state).observation.action_mask
+
+    def _obs_from_grid(self, grid: torch.Tensor) -> torch.Tensor:
+        """(m, m) -> (N, m, m): every agent's view with itself as wire 0."""
+        batched = grid.dim() == 3
+        B = grid.shape[0] if batched else 1
+        dev, N = grid.device, self.num_agents
+        z = torch.zeros((B, N, 2) if batched else (N, 2), dtype=torch.int32, device=dev)
+        agents = Agent(id=torch.arange(N, dtype=torch.int32, device=dev), start=z, target=z - 1, position=z)
+        state = State(grid=grid, step_count=torch.zeros((B,) if batched else (), dtype=torch.int32, device=dev),
+                      agents=agents,
+                      key=torch.zeros((B, 2) if batched else (2,), dtype=torch.uint32, device=dev))
+        return self._timestep_of(state).observation.grid
+
+    def _get_extras(self, state: State):
+        return self._timestep_of(state).extras

@@ -1,0 +1,54 @@
+"""[3P] jumanji.wrappers.{VmapAutoResetWrapper, MultiToSingleWrapper} as used at
+routing_board_generation/rl_training/setup_train.py:158-167.
+
+The native env is already batched, so VmapAutoResetWrapper only switches on the fused auto-reset
+of `rbg_connector_step`; MultiToSingleWrapper aggregates per-agent reward (sum) and discount (max).
+"""
+from typing import Tuple
+
+import torch
+
+from ..types import State, TimeStep
+
+
+class _Wrapper:
+    def __init__(self, env):
+        self._env = env
+
+    def __getattr__(self, name):
+        return getattr(self._env, name)
+
+    @property
+    def unwrapped(self):
+        return self._env.unwrapped
+
+
+class MultiToSingleWrapper(_Wrapper):
+    def _aggregate(self, ts: TimeStep) -> TimeStep:
+        return ts._replace(reward=ts.reward.sum(dim=-1), discount=ts.discount.max(dim=-1).values)
+
+    def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
+        state, ts = self._env.reset(key)
+        return state, self._aggregate(ts)
+
+    def step(self, state: State, action: torch.Tensor) -> Tuple[State, TimeStep]:
+        state, ts = self._env.step(state, action)
+        return state, self._aggregate(ts)
+
+
+class VmapAutoResetWrapper(_Wrapper):
+    """reset(keys (B, 2)) / step(batched state, action (B, N)); finished episodes restart inside
+    the same kernel launch from split(state.key)[0], keeping reward/discount/step_type/extras of
+    the terminal step and replacing only the observation."""
+
+    def __init__(self, env):
+        super().__init__(env)
+        env.unwrapped._auto_reset = True
+
+    def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
+        if key.dim() != 2:
+            raise ValueError("VmapAutoResetWrapper.reset expects keys of shape (B, 2)")
+        return self._env.reset(key)
+
+    def step(self, state: State, action: torch.Tensor) -> Tuple[State, TimeStep]:
+        return self._env.step(state, action)

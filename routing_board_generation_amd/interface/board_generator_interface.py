@@ -1,0 +1,54 @@
+"""Name -> generator-class registry; mirrors routing_board_generation/interface/
+board_generator_interface.py:32-71 for the boards this package implements.
+
+Only `offline_parallel_rw` is on the hot path; the other names of the
+reference enum are kept so that `BoardName(value)` parses every string the reference accepts,
+but asking for their class raises NotImplementedError instead of importing a NumPy zoo.
+"""
+from enum import Enum
+
+from ..board_generation.parallel_random_walk import ParallelRandomWalkBoard
+
+
+class BoardName(str, Enum):
+    RANDOM_WALK = "random_walk"
+    BFS_BASE = "bfs_base"
+    BFS_MIN_BENDS = "bfs_min_bend"
+    BFS_FIFO = "bfs_fifo"
+    BFS_SHORTEST = "bfs_short"
+    BFS_LONGEST = "bfs_long"
+    LSYSTEMS = "lsystems_standard"
+    WFC = "wfc"
+    NUMBERLINK = "numberlink"
+
+    JAX_PARALLEL_RW = "offline_parallel_rw"
+    JAX_SEED_EXTENSION = "offline_seed_extension"
+
+
+class BoardGenerator:
+    """Maps BoardName to the class of the generator."""
+
+    board_generator_dict = {
+        BoardName.JAX_PARALLEL_RW: ParallelRandomWalkBoard,
+    }
+
+    @classmethod
+    def get_board_generator(cls, board_enum: BoardName):
+        try:
+            return cls.board_generator_dict[BoardName(board_enum)]
+        except KeyError:
+            raise NotImplementedError(
+                f"{board_enum!r} is outside the MI355X hot path of this package "
+                "(only 'offline_parallel_rw' is implemented natively)") from None
+
+
+def make_online_generator(generation_type: str, grid_size: int, num_agents: int):
+    """The `online_*` branch of setup_train._make_raw_env
+    (routing_board_generation/rl_training/setup_train.py:131-152)."""
+    from ..online_generators import ParallelRandomWalkGenerator, UniformRandomGenerator
+
+    if generation_type == "online_parallel_rw":
+        return ParallelRandomWalkGenerator(grid_size=grid_size, num_agents=num_agents)
+    if generation_type == "online_uniform":
+        return UniformRandomGenerator(grid_size=grid_size, num_agents=num_agents)
+    raise NotImplementedError(f"generation_type {generation_type!r} is outside the hot path")

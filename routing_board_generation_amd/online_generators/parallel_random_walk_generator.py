@@ -1,0 +1,28 @@
+"""ParallelRandomWalkGenerator -- mirrors routing_board_generation/rl_training/
+online_generators/parallel_random_walk_generator.py:29-77."""
+import torch
+
+from .. import ops
+from ..board_generation.parallel_random_walk import ParallelRandomWalkBoard
+from ..types import State
+from .uniform_generator import Generator, state_from_bufs
+
+
+class ParallelRandomWalkGenerator(Generator):
+    """Generates solvable `Connector` boards with the parallel random walk."""
+
+    def __init__(self, grid_size: int, num_agents: int) -> None:
+        super().__init__(grid_size, num_agents)
+        self.board_generator = ParallelRandomWalkBoard(self.grid_size, self.grid_size,
+                                                       self.num_agents)
+
+    def __call__(self, key: torch.Tensor) -> State:
+        batched = key.dim() == 2
+        keys = key if batched else key[None]
+        B, dev = keys.shape[0], keys.device
+        out = ops.prw_generate(keys.contiguous(), self.grid_size, self.num_agents,
+                               split_first=True, want_solved=False, want_train=True)
+        st = {"grid": out["train_grid"], "start": out["start"], "target": out["target"],
+              "position": out["start"].clone(), "key": out["key_out"],
+              "step_count": torch.zeros((B,), dtype=torch.int32, device=dev)}
+        return state_from_bufs(st, batched)

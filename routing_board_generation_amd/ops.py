@@ -1,0 +1,221 @@
+"""Tensor-level launchers: torch device tensors in, C-ABI calls on torch's current HIP stream.
+
+PyTorch is used for device memory and streams only; every value below is produced by the HIP
+kernels of csrc/prw_kernels.hip.  All functions are batched ([B, ...]) and asynchronous.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _native as nat
+
+StateBufs = Dict[str, torch.Tensor]
+TimestepBufs = Dict[str, torch.Tensor]
+
+STATE_FIELDS = ("grid", "step_count", "start", "target", "position", "key")
+TIMESTEP_FIELDS = ("step_type", "reward", "discount", "obs_grid", "action_mask",
+                   "obs_step_count", "num_connections", "ratio_connections", "total_path_length")
+
+
+def _stream(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _check(t: torch.Tensor, dtype: torch.dtype, shape, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on a HIP device (got {t.device}); this package has "
+                         "no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def check_keys(keys: torch.Tensor) -> torch.Tensor:
+    if keys.dim() != 2 or keys.shape[1] != 2:
+        raise ValueError(f"keys must have shape [B, 2], got {tuple(keys.shape)}")
+    return _check(keys, torch.uint32, keys.shape, "keys")
+
+
+def alloc_state(B: int, m: int, N: int, device) -> StateBufs:
+    i32 = dict(dtype=torch.int32, device=device)
+    return {
+        "grid": torch.empty((B, m, m), **i32),
+        "step_count": torch.empty((B,), **i32),
+        "start": torch.empty((B, N, 2), **i32),
+        "target": torch.empty((B, N, 2), **i32),
+        "position": torch.empty((B, N, 2), **i32),
+        "key": torch.empty((B, 2), dtype=torch.uint32, device=device),
+    }
+
+
+def alloc_timestep(B: int, m: int, N: int, device, with_obs_grid: bool = True) -> TimestepBufs:
+    ts = {
+        "step_type": torch.empty((B,), dtype=torch.int8, device=device),
+        "reward": torch.empty((B, N), dtype=torch.float32, device=device),
+        "discount": torch.empty((B, N), dtype=torch.float32, device=device),
+        "action_mask": torch.empty((B, N, 5), dtype=torch.bool, device=device),
+        "obs_step_count": torch.empty((B,), dtype=torch.int32, device=device),
+        "num_connections": torch.empty((B,), dtype=torch.int32, device=device),
+        "ratio_connections": torch.empty((B,), dtype=torch.float32, device=device),
+        "total_path_length": torch.empty((B,), dtype=torch.int32, device=device),
+    }
+    if with_obs_grid:
+        ts["obs_grid"] = torch.empty((B, N, m, m), dtype=torch.int32, device=device)
+    return ts
+
+
+def _state_struct(st: StateBufs, B: int, m: int, N: int) -> nat.State:
+    _check(st["grid"], torch.int32, (B, m, m), "state.grid")
+    _check(st["step_count"], torch.int32, (B,), "state.step_count")
+    for f in ("start", "target", "position"):
+        _check(st[f], torch.int32, (B, N, 2), f"state.agents.{f}")
+    _check(st["key"], torch.uint32, (B, 2), "state.key")
+    return nat.State(*[st[f].data_ptr() for f in STATE_FIELDS])
+
+
+def _timestep_struct(ts: TimestepBufs, B: int, m: int, N: int) -> nat.Timestep:
+    shapes = {
+        "step_type": (torch.int8, (B,)), "reward": (torch.float32, (B, N)),
+        "discount": (torch.float32, (B, N)), "obs_grid": (torch.int32, (B, N, m, m)),
+        "action_mask": (torch.bool, (B, N, 5)), "obs_step_count": (torch.int32, (B,)),
+        "num_connections": (torch.int32, (B,)), "ratio_connections": (torch.float32, (B,)),
+        "total_path_length": (torch.int32, (B,)),
+    }
+    ptrs = []
+    for f in TIMESTEP_FIELDS:
+        t = ts.get(f)
+        if t is not None:
+            _check(t, shapes[f][0], shapes[f][1], f"timestep.{f}")
+        ptrs.append(_ptr(t))
+    return nat.Timestep(*ptrs)
+
+
+# ------------------------------------------------------------------------------------- PRNG
+def split(key0: int, key1: int, num: int, device) -> torch.Tensor:
+    out = torch.empty((num, 2), dtype=torch.uint32, device=device)
+    nat.check(nat.lib().rbg_split(key0, key1, num, out.data_ptr(), _stream(out.device)),
+              "rbg_split")
+    return out
+
+
+def split_batch(keys: torch.Tensor, num: int) -> torch.Tensor:
+    keys = check_keys(keys)
+    B = keys.shape[0]
+    out = torch.empty((B, num, 2), dtype=torch.uint32, device=keys.device)
+    nat.check(nat.lib().rbg_split_batch(keys.data_ptr(), B, num, out.data_ptr(),
+                                        _stream(keys.device)), "rbg_split_batch")
+    return out
+
+
+# ------------------------------------------------------------------------------------- generators
+def prw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool, want_solved: bool = True,
+                 want_train: bool = True, want_iters: bool = False, out: Optional[dict] = None):
+    """Returns dict(solved_grid?, train_grid?, start, target, key_out, iters?)."""
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    o = out if out is not None else {}
+    if want_solved and "solved_grid" not in o:
+        o["solved_grid"] = torch.empty((B, m, m), **i32)
+    if want_train and "train_grid" not in o:
+        o["train_grid"] = torch.empty((B, m, m), **i32)
+    if "start" not in o:
+        o["start"] = torch.empty((B, N, 2), **i32)
+    if "target" not in o:
+        o["target"] = torch.empty((B, N, 2), **i32)
+    if "key_out" not in o:
+        o["key_out"] = torch.empty((B, 2), dtype=torch.uint32, device=dev)
+    if want_iters and "iters" not in o:
+        o["iters"] = torch.empty((B,), **i32)
+    for f in ("solved_grid", "train_grid"):
+        if f in o:
+            _check(o[f], torch.int32, (B, m, m), f)
+    _check(o["start"], torch.int32, (B, N, 2), "start")
+    _check(o["target"], torch.int32, (B, N, 2), "target")
+    _check(o["key_out"], torch.uint32, (B, 2), "key_out")
+    nat.check(nat.lib().rbg_prw_generate(
+        keys.data_ptr(), B, m, N, int(split_first), _ptr(o.get("solved_grid")),
+        _ptr(o.get("train_grid")), o["start"].data_ptr(), o["target"].data_ptr(),
+        o["key_out"].data_ptr(), _ptr(o.get("iters")), _stream(dev)), "rbg_prw_generate")
+    return o
+
+
+def uniform_generate(keys: torch.Tensor, m: int, N: int) -> StateBufs:
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    st = alloc_state(B, m, N, dev)
+    nat.check(nat.lib().rbg_uniform_generate(
+        keys.data_ptr(), B, m, N, st["grid"].data_ptr(), st["start"].data_ptr(),
+        st["target"].data_ptr(), st["key"].data_ptr(), _stream(dev)), "rbg_uniform_generate")
+    st["position"] = st["start"].clone()
+    st["step_count"].zero_()
+    return st
+
+
+# ------------------------------------------------------------------------------------- Connector
+def connector_reset(keys: torch.Tensor, m: int, N: int, state: Optional[StateBufs] = None,
+                    timestep: Optional[TimestepBufs] = None):
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    st = state if state is not None else alloc_state(B, m, N, dev)
+    ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
+    s, t = _state_struct(st, B, m, N), _timestep_struct(ts, B, m, N)
+    nat.check(nat.lib().rbg_connector_reset(keys.data_ptr(), B, m, N, C.byref(s), C.byref(t),
+                                            _stream(dev)), "rbg_connector_reset")
+    return st, ts
+
+
+def connector_observe(state: StateBufs, timestep: Optional[TimestepBufs] = None):
+    B, m, _ = state["grid"].shape
+    N = state["start"].shape[1]
+    dev = state["grid"].device
+    ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
+    s, t = _state_struct(state, B, m, N), _timestep_struct(ts, B, m, N)
+    nat.check(nat.lib().rbg_connector_observe(B, m, N, C.byref(s), C.byref(t), _stream(dev)),
+              "rbg_connector_observe")
+    return ts
+
+
+def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
+                   timestep_reward: float = -0.03, connected_reward: float = 0.1,
+                   auto_reset: bool = False, state_out: Optional[StateBufs] = None,
+                   timestep: Optional[TimestepBufs] = None):
+    """state_out=None allocates a fresh state (functional); pass state_out=state to step in place."""
+    B, m, _ = state["grid"].shape
+    N = state["start"].shape[1]
+    dev = state["grid"].device
+    _check(action, torch.int32, (B, N), "action")
+    so = state_out if state_out is not None else alloc_state(B, m, N, dev)
+    ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
+    si, s_o = _state_struct(state, B, m, N), _state_struct(so, B, m, N)
+    t = _timestep_struct(ts, B, m, N)
+    p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
+                      int(bool(auto_reset)))
+    nat.check(nat.lib().rbg_connector_step(B, m, N, C.byref(si), C.byref(s_o), action.data_ptr(),
+                                           C.byref(p), C.byref(t), _stream(dev)),
+              "rbg_connector_step")
+    return so, ts
+
+
+def random_actions(keys: torch.Tensor, t: int, action_mask: torch.Tensor,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    keys = check_keys(keys)
+    B, N, _ = action_mask.shape
+    _check(action_mask, torch.bool, (B, N, 5), "action_mask")
+    if keys.shape[0] != B:
+        raise ValueError("keys and action_mask disagree on B")
+    act = out if out is not None else torch.empty((B, N), dtype=torch.int32, device=keys.device)
+    _check(act, torch.int32, (B, N), "action")
+    nat.check(nat.lib().rbg_random_actions(keys.data_ptr(), B, N, int(t) & 0xFFFFFFFF,
+                                           action_mask.data_ptr(), act.data_ptr(),
+                                           _stream(keys.device)), "rbg_random_actions")
+    return act

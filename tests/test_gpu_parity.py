@@ -1,0 +1,332 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the reference's goldens and against
+the CPU oracle on the same seeded inputs.  Bit-exact everywhere: grids, indices, keys and trip
+counts are integers; rewards/discounts/ratios are single IEEE float32 operations.
+
+Run on the GPU box with `python -m pytest tests -m gpu`.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import (assert_dicts_equal, check_solved_boards, state_to_np, timestep_to_np, to_np)
+
+pytestmark = pytest.mark.gpu
+
+WINDOW = [0, 1, 2, 7, 8, 9]
+WINDOW_BOARDS = [0, 1, 2, 97, 98, 99]
+
+
+@pytest.fixture(scope="module")
+def rbg():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (there is no CPU fallback to hide behind)")
+    import routing_board_generation_amd as pkg
+
+    pkg._native.lib()  # raises if the in-tree .so is missing
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    return torch
+
+
+def _keys(rbg, seed, B):
+    return rbg.split(rbg.PRNGKey(seed), B)
+
+
+# ------------------------------------------------------------------------------ PRNG
+def test_split_matches_oracle_and_known_answer(rbg, oracle):
+    ks = to_np(rbg.split(rbg.PRNGKey(0)))
+    assert ks.tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    for num in (1, 3, 7, 100, 4096):
+        assert (to_np(rbg.split(rbg.PRNGKey(5), num)) == oracle.split(oracle.prng_key(5), num)).all()
+    big = rbg.PRNGKey((123 << 32) | 77)
+    assert to_np(big).tolist() == [123, 77]
+
+
+def test_split_batch_matches_oracle(rbg, oracle):
+    keys = _keys(rbg, 1, 33)
+    got = to_np(rbg.split(keys, 3))
+    exp = np.stack([oracle.split(k, 3) for k in to_np(keys)])
+    assert (got == exp).all()
+
+
+# ------------------------------------------------------------------------------ reference goldens
+def test_generate_board_golden_5x5(rbg, goldens):
+    """JAXI/test_parallel_random_walk_board.py::test_generate_board (key = PRNGKey(0))."""
+    tf = goldens["test_file"]
+    board = rbg.ParallelRandomWalkBoard(rows=5, cols=5, num_agents=3)
+    heads, targets, grid = board.generate_board(rbg.PRNGKey(0))
+    exp = tf["agents_reshaped_for_generator"]
+    assert (to_np(grid) == np.asarray(tf["valid_end_grid2"])).all()
+    assert (to_np(heads) == np.asarray(exp["start"])).all()
+    assert (to_np(targets) == np.asarray(exp["position"])).all()
+
+
+def test_generate_board_for_various_keys(rbg):
+    """::test_generate_board_for_various_keys -- ten seeds give ten different boards."""
+    board = rbg.ParallelRandomWalkBoard(5, 5, 3)
+    boards = [to_np(board.generate_board(rbg.PRNGKey(i))[2]) for i in range(10)]
+    for i in range(10):
+        for j in range(i):
+            assert not (boards[i] == boards[j]).all()
+
+
+@pytest.mark.parametrize("name", ["parallel_random_walk", "uniform"])
+def test_single_board_generators_golden(rbg, goldens, name):
+    """profiling_generators.ipynb cells 13 / 4: generator(10, 5)(PRNGKey(0))."""
+    s = goldens["notebook"]["single_10x10_5_PRNGKey0"][name]
+    gen = {"parallel_random_walk": rbg.ParallelRandomWalkGenerator,
+           "uniform": rbg.UniformRandomGenerator}[name](10, 5)
+    state = gen(rbg.PRNGKey(0))
+    assert (to_np(state.grid) == np.asarray(s["grid"])).all()
+    assert (to_np(state.agents.start) == np.asarray(s["start"])).all()
+    assert (to_np(state.agents.target) == np.asarray(s["target"])).all()
+    assert (to_np(state.agents.position) == np.asarray(s["position"])).all()
+    assert (to_np(state.agents.id) == np.arange(5)).all()
+    assert (to_np(state.key) == np.asarray(s["key"], np.uint32)).all()
+    assert int(state.step_count) == 0
+
+
+@pytest.mark.parametrize("name", ["parallel_random_walk", "uniform"])
+def test_batch100_generators_golden(rbg, goldens, name):
+    """profiling_generators.ipynb cells 26 / 18: vmap(generator)(split(PRNGKey(0), 100))."""
+    b = goldens["notebook"]["batch100_10x10_5_split_PRNGKey0"][name]
+    gen = {"parallel_random_walk": rbg.ParallelRandomWalkGenerator,
+           "uniform": rbg.UniformRandomGenerator}[name](10, 5)
+    state = gen(_keys(rbg, 0, 100))
+    assert (to_np(state.agents.start) == np.asarray(b["start"])).all()
+    assert (to_np(state.agents.target) == np.asarray(b["target"])).all()
+    assert (to_np(state.agents.position) == np.asarray(b["position"])).all()
+    assert (to_np(state.key) == np.asarray(b["key"], np.uint32)).all()
+    win = to_np(state.grid)[WINDOW_BOARDS][:, WINDOW][:, :, WINDOW]
+    assert (win == np.asarray(b["grid_window"])).all()
+
+
+# ------------------------------------------------------------------------------ oracle parity
+CONFIGS = [
+    # (m, N, B, seed)          BASELINE configs: C1 8x8/5/B=1, C2 16x16/10/4096, C4 shape 32x32/20
+    (8, 5, 1, 0), (16, 10, 4096, 0), (32, 20, 256, 0),
+    (5, 3, 64, 1), (10, 5, 100, 0), (7, 4, 37, 2), (9, 9, 50, 3), (2, 1, 5, 4), (3, 9, 6, 5),
+    (12, 64, 16, 6), (40, 64, 8, 7), (33, 17, 9, 8), (16, 1, 7, 9), (4, 16, 3, 10),
+]
+
+
+@pytest.mark.parametrize("m,N,B,seed", CONFIGS)
+def test_prw_generator_matches_oracle(rbg, oracle, m, N, B, seed):
+    from routing_board_generation_amd import ops
+
+    keys = _keys(rbg, seed, B)
+    out = ops.prw_generate(keys, m, N, split_first=True, want_solved=True, want_train=True,
+                           want_iters=True)
+    st, solved, iters = oracle.generate_batch(to_np(keys), m, N, threads=8)
+    got = {"grid": to_np(out["train_grid"]), "start": to_np(out["start"]),
+           "target": to_np(out["target"]), "key": to_np(out["key_out"])}
+    assert_dicts_equal(got, {k: st[k] for k in got}, f"{m}x{m}/{N}: ")
+    assert (to_np(out["solved_grid"]) == solved).all()
+    assert (to_np(out["iters"]) == iters).all()
+
+
+@pytest.mark.parametrize("m,N,B,seed", [(8, 5, 1, 0), (16, 10, 512, 3), (10, 5, 100, 0)])
+def test_generate_board_matches_oracle(rbg, oracle, m, N, B, seed):
+    keys = _keys(rbg, seed, B)
+    heads, targets, grid, iters = rbg.ParallelRandomWalkBoard(m, m, N).generate_board_with_stats(keys)
+    eh, et, es, ei = oracle.generate_board_batch(to_np(keys), m, N, threads=8)
+    assert (to_np(heads) == eh.transpose(0, 2, 1)).all()
+    assert (to_np(targets) == et.transpose(0, 2, 1)).all()
+    assert (to_np(grid) == es).all()
+    assert (to_np(iters) == ei).all()
+
+
+def test_c2_batch_digests(rbg):
+    """SHA-256 digests of the full BASELINE config-2 batch (derived
+    cross-check data reproduced independently by the survey's emulation and by oracle/)."""
+    from routing_board_generation_amd import ops
+
+    out = ops.prw_generate(_keys(rbg, 0, 4096), 16, 10, split_first=True, want_iters=True)
+    h = lambda t: hashlib.sha256(np.ascontiguousarray(to_np(t)).tobytes()).hexdigest()  # noqa
+    assert h(out["train_grid"]) == "0a4e49ce3c80f710914af2143a28d6a25b32add93a6627e6a35fc0bd58204dfb"
+    assert h(out["solved_grid"]) == "1b3383bf42acab1b1c4d3a43f5de126d7fe82b2e3778ea4fb93ce17b39f528ca"
+    assert h(out["start"]) == "abdb3d790655b09f4e241936096ba476c6ac7b03be0a9c551137d166f7805ee6"
+    assert h(out["target"]) == "34c740bd17c08aa8ef3893431e025b5c6563a679ae440185a148cfeb90802405"
+    assert h(out["key_out"]) == "44f6f43143cc8f114be60dbb5ac4356f9a95790877396ef645e6fe8efe2444b5"
+    assert h(out["iters"]) == "a847c96372f12e9b11e4c1c67ad5d98192c26d18c0a1e979df0889acb08ea5dc"
+
+
+@pytest.mark.parametrize("m,N,B", [(16, 10, 4096), (32, 20, 4096)])
+def test_full_size_properties(rbg, m, N, B):
+    """Size-independent properties at BASELINE's full per-GPU sizes (C2, C4's per-GPU shard):
+    wire validity of every solved board, training grid = heads + targets only, determinism,
+    and shard invariance (a key range gives the same boards whichever batch it is part of)."""
+    from routing_board_generation_amd import ops
+
+    keys = _keys(rbg, 0, B)
+    out = ops.prw_generate(keys, m, N, split_first=True, want_iters=True)
+    solved, train = to_np(out["solved_grid"]), to_np(out["train_grid"])
+    start, target, iters = to_np(out["start"]), to_np(out["target"]), to_np(out["iters"])
+    check_solved_boards(solved, start, target)
+    assert (train == np.where((solved % 3) == 1, 0, solved)).all()
+    assert (iters >= 1).all() and (iters <= m * m - N).all()
+    again = ops.prw_generate(keys, m, N, split_first=True)
+    assert (to_np(again["solved_grid"]) == solved).all()
+    lo, hi = B // 8 * 3, B // 8 * 4  # "rank 3 of 8"
+    shard = ops.prw_generate(keys[lo:hi].contiguous(), m, N, split_first=True)
+    assert (to_np(shard["solved_grid"]) == solved[lo:hi]).all()
+    assert (to_np(shard["target"]) == target[lo:hi]).all()
+
+
+@pytest.mark.parametrize("B", [0, 1, 2, 3, 5, 63, 65])
+def test_ragged_batch_sizes(rbg, oracle, B, torch_mod):
+    from routing_board_generation_amd import ops
+
+    if B == 0:
+        keys = torch_mod.empty((0, 2), dtype=torch_mod.uint32, device="cuda")
+        out = ops.prw_generate(keys, 16, 10, split_first=True)
+        assert out["solved_grid"].shape == (0, 16, 16)
+        return
+    keys = _keys(rbg, 11, B)
+    out = ops.prw_generate(keys, 16, 10, split_first=True)
+    st, solved, _ = oracle.generate_batch(to_np(keys), 16, 10)
+    assert (to_np(out["solved_grid"]) == solved).all()
+    assert (to_np(out["target"]) == st["target"]).all()
+
+
+# ------------------------------------------------------------------------------ Connector
+@pytest.mark.parametrize("m,N,B", [(16, 10, 256), (10, 5, 100), (7, 4, 19), (32, 20, 32)])
+def test_connector_reset_matches_oracle(rbg, oracle, m, N, B):
+    env = rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N))
+    keys = _keys(rbg, 2, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle.connector_reset_batch(to_np(keys), m, N, threads=8)
+    assert_dicts_equal(state_to_np(state), est, "state.")
+    assert_dicts_equal(timestep_to_np(ts), ets, "timestep.")
+    assert (to_np(ts.first())).all()
+
+
+def test_connector_reset_single_env_shapes(rbg, oracle):
+    env = rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(10, 5))
+    state, ts = env.reset(rbg.PRNGKey(0))
+    assert state.grid.shape == (10, 10) and state.agents.start.shape == (5, 2)
+    assert ts.observation.grid.shape == (5, 10, 10) and ts.observation.action_mask.shape == (5, 5)
+    assert ts.reward.shape == (5,) and ts.step_type.shape == ()
+    est, ets = oracle.connector_reset_batch(oracle.prng_key(0)[None], 10, 5)
+    assert (to_np(ts.observation.grid) == ets["obs_grid"][0]).all()
+    assert (to_np(state.grid) == est["grid"][0]).all()
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+@pytest.mark.parametrize("m,N,B,steps", [(16, 10, 128, 60), (10, 5, 64, 60), (7, 4, 21, 25)])
+def test_connector_rollout_matches_oracle(rbg, oracle, torch_mod, m, N, B, steps, auto_reset):
+    """Random-legal-action rollout: state and timestep are compared after EVERY step, through
+    connection events, collisions, blocked agents, the time limit and (auto_reset) fused resets."""
+    from routing_board_generation_amd import ops
+
+    env = rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), time_limit=20)
+    if auto_reset:
+        env = rbg.VmapAutoResetWrapper(env)
+    keys = _keys(rbg, 4, B)
+    akeys = _keys(rbg, 1, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle.connector_reset_batch(to_np(keys), m, N, threads=8)
+    n_last = 0
+    for t in range(steps):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        assert (to_np(action) == eaction).all(), f"policy diverged at step {t}"
+        state, ts = env.step(state, action)
+        ets = oracle.connector_step_batch(est, eaction, time_limit=20, auto_reset=auto_reset,
+                                          threads=8)
+        assert_dicts_equal(state_to_np(state), est, f"step {t} state.")
+        assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
+        n_last += int(to_np(ts.last()).sum())
+    assert n_last > 0, "the rollout never reached a terminal step"
+    if auto_reset:
+        assert int(to_np(state.step_count).max()) <= 20
+
+
+def test_connector_step_in_place_and_out_of_place_agree(rbg, torch_mod):
+    from routing_board_generation_amd import ops
+
+    keys = _keys(rbg, 8, 64)
+    st, ts = ops.connector_reset(keys, 16, 10)
+    action = ops.random_actions(keys, 0, ts["action_mask"])
+    out_state, out_ts = ops.connector_step(st, action)
+    inplace = {k: v.clone() for k, v in st.items()}
+    _, in_ts = ops.connector_step(inplace, action, state_out=inplace)
+    for k in out_state:
+        assert torch_mod.equal(out_state[k].view(torch_mod.int32) if k == "key" else out_state[k],
+                               inplace[k].view(torch_mod.int32) if k == "key" else inplace[k]), k
+    assert torch_mod.equal(out_ts["obs_grid"], in_ts["obs_grid"])
+
+
+def test_collision_kat_through_connector_step(rbg, torch_mod):
+    """SURVEY.md 4.2 collision KAT (hand-derived from JAXI/parallel_random_walk.py:104-107,128):
+    two and three agents contest one cell; the highest id wins, the others stay untouched."""
+    from routing_board_generation_amd import ops
+
+    dev = "cuda"
+    grid = torch_mod.zeros((2, 5, 5), dtype=torch_mod.int32, device=dev)
+    for b in range(2):
+        grid[b, 2, 0], grid[b, 2, 1], grid[b, 2, 3], grid[b, 1, 2] = 1, 2, 5, 8
+    pos = torch_mod.tensor([[[2, 1], [2, 3], [1, 2]]] * 2, dtype=torch_mod.int32, device=dev)
+    st = {"grid": grid, "step_count": torch_mod.zeros(2, dtype=torch_mod.int32, device=dev),
+          "start": pos.clone(), "target": torch_mod.full_like(pos, -1), "position": pos.clone(),
+          "key": torch_mod.zeros((2, 2), dtype=torch_mod.uint32, device=dev)}
+    action = torch_mod.tensor([[2, 4, 0], [2, 4, 3]], dtype=torch_mod.int32, device=dev)
+    so, _ = ops.connector_step(st, action)
+    g = to_np(so["grid"])
+    assert g[0, 2].tolist() == [1, 2, 5, 4, 0]
+    assert to_np(so["position"])[0].tolist() == [[2, 1], [2, 2], [1, 2]]
+    assert g[1, 1].tolist() == [0, 0, 7, 0, 0]
+    assert g[1, 2].tolist() == [1, 2, 8, 5, 0]
+    assert to_np(so["position"])[1].tolist() == [[2, 1], [2, 3], [2, 2]]
+
+
+def test_private_env_methods_used_by_the_reference(rbg, oracle):
+    """demos/board_generator_demo.py:80-96 builds a TimeStep by hand from _get_action_mask,
+    _obs_from_grid and _get_extras."""
+    env = rbg.Connector(generator=rbg.UniformRandomGenerator(10, 5))
+    state = rbg.UniformRandomGenerator(10, 5)(rbg.PRNGKey(3))
+    mask = env._get_action_mask(state.agents, state.grid)
+    obs = env._obs_from_grid(state.grid)
+    extras = env._get_extras(state)
+    est, _, _ = oracle.generate_batch(oracle.prng_key(3)[None], 10, 5, generator="uniform")
+    ets = oracle.connector_observe_batch(est)
+    assert (to_np(mask).astype(np.uint8) == ets["action_mask"][0]).all()
+    assert (to_np(obs) == ets["obs_grid"][0]).all()
+    assert int(extras["num_connections"]) == int(ets["num_connections"][0])
+    assert int(extras["total_path_length"]) == 0
+
+
+def test_uniform_generator_env_with_generic_auto_reset(rbg, oracle):
+    """A Generator without a fused kernel goes through generator(key) + rbg_connector_observe."""
+    env = rbg.VmapAutoResetWrapper(rbg.MultiToSingleWrapper(
+        rbg.Connector(generator=rbg.UniformRandomGenerator(8, 4), time_limit=3)))
+    keys = _keys(rbg, 6, 32)
+    state, ts = env.reset(keys)
+    assert ts.reward.shape == (32,)
+    import torch
+
+    for _ in range(3):
+        state, ts = env.step(state, torch.zeros((32, 4), dtype=torch.int32, device="cuda"))
+    assert to_np(ts.last()).all()           # time limit reached with NOOPs
+    assert (to_np(state.step_count) == 0).all()  # and every env was regenerated
+    exp_keys = np.stack([oracle.split(oracle.split(oracle.split(k)[0])[0])[0] for k in to_np(keys)])
+    assert (to_np(state.key) == exp_keys).all()
+
+
+def test_registry(rbg):
+    from routing_board_generation_amd.interface.board_generator_interface import make_online_generator
+
+    cls = rbg.BoardGenerator.get_board_generator(rbg.BoardName("offline_parallel_rw"))
+    assert cls is rbg.ParallelRandomWalkBoard
+    with pytest.raises(NotImplementedError):
+        rbg.BoardGenerator.get_board_generator(rbg.BoardName("wfc"))
+    gen = make_online_generator("online_parallel_rw", 16, 10)
+    assert isinstance(gen, rbg.ParallelRandomWalkGenerator) and gen.grid_size == 16

@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every symbol declared in
+include/rbg_prw.h, and rejects bad arguments before touching the GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from routing_board_generation_amd import _native
+
+    _native.build_native()
+    return _native
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "rbg_prw.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rbg_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_functions_are_exported_and_bound(native):
+    declared = _declared_functions()
+    assert len(declared) >= 11
+    handle = C.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in rbg_prw.h but not exported"
+    assert sorted(native.SIGNATURES) == declared, "ctypes binding out of sync with the header"
+
+
+def test_version_and_abi(native):
+    lib = native.lib()
+    assert lib.rbg_abi_version() == native.ABI_VERSION
+    assert b"gfx950" in lib.rbg_version()
+
+
+def test_struct_layouts_match_header(native):
+    assert C.sizeof(native.State) == 6 * C.sizeof(C.c_void_p)
+    assert C.sizeof(native.Timestep) == 9 * C.sizeof(C.c_void_p)
+    assert C.sizeof(native.EnvParams) == 16
+
+
+def test_argument_errors_do_not_need_a_gpu(native):
+    lib = native.lib()
+    assert lib.rbg_prw_generate(None, 1, 16, 10, 1, None, None, None, None, None, None, None) == -1
+    assert b"NULL" in lib.rbg_last_error()
+    one = C.c_void_p(16)  # never dereferenced: shape checks come first
+    assert lib.rbg_prw_generate(one, 1, 41, 10, 1, None, None, one, one, None, None, None) == -2
+    assert lib.rbg_prw_generate(one, 1, 16, 65, 1, None, None, one, one, None, None, None) == -2
+    assert lib.rbg_prw_generate(one, 1, 3, 10, 1, None, None, one, one, None, None, None) == -2
+    assert lib.rbg_prw_generate(one, -1, 16, 10, 1, None, None, one, one, None, None, None) == -2
+    assert lib.rbg_uniform_generate(one, 1, 4, 9, None, one, one, None, None) == -2
+    assert lib.rbg_split(0, 0, 4, None, None) == -1
+    with pytest.raises(native.NativeLibraryError):
+        native.check(-2, "rbg_prw_generate")
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no file of the package may reference it."""
+    pkg = os.path.join(ROOT, "routing_board_generation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), (
+                    f"{os.path.join(dirpath, f)} mentions the oracle")
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    import torch
+
+    from routing_board_generation_amd import ops
+
+    keys = torch.zeros((4, 2), dtype=torch.uint32)
+    with pytest.raises(ValueError, match="no CPU path"):
+        ops.prw_generate(keys, 16, 10, split_first=True)
