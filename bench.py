@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- boards/s of the ParallelRandomWalk generator hot path on N MI355X GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: ParallelRandomWalkGenerator(16, 10) vmapped
+over 4096 keys per GPU (BASELINE.json configs[1]), producing the full Connector State in HBM.
+Keys are `split(PRNGKey(0), 4096 * n_gpus)` sharded contiguously over the ranks (weak scaling:
+per-GPU work is fixed), already resident in HBM when the timed region starts.
+
+Rank 0 prints ONE JSON line.  Besides the driver contract it carries
+  roofline      achieved algorithmic GB/s of the dominant kernel (prw_generate_kernel) against the
+                HBM peak, from HIP-event durations measured live around every launch
+  cpu_baseline  the CPU oracle (a port, oracle/prw_oracle.c) timed on this box's host cores on a
+                bounded sample of the same workload
+  env_step      the Connector.step rollout of BASELINE configs[2] (16x16/10, batch 4096, random
+                legal actions, fused auto-reset) with its own HBM roofline -- reported beside the
+                headline, never folded into `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GRID, AGENTS, BATCH_PER_GPU = 16, 10, 4096
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def generator_bytes_per_board(m: int, N: int) -> int:
+    """Algorithmic HBM bytes of one generated State (minus Agent.id which is an
+    arange that is never materialised): key in + training grid + start/target/position +
+    step_count + key out."""
+    return 8 + 4 * m * m + 3 * 8 * N + 4 + 8
+
+
+def env_step_bytes(m: int, N: int) -> int:
+    """Algorithmic HBM bytes of one env step: read grid + agents + step_count +
+    key + action; write the same state + observation (N x m x m) + mask + reward + discount +
+    step_type + extras."""
+    read = 4 * m * m + 24 * N + 4 + 8 + 4 * N
+    write = 4 * m * m + 24 * N + 4 + 8 + 4 * N * m * m + 5 * N + 8 * N + 1 + 4 + 12
+    return read + write
+
+
+def cpu_baseline(sample_batches: int):
+    """Oracle (CPU port of the reference algorithm) on the same workload, all host threads."""
+    import numpy as np  # noqa: F401
+
+    from oracle import oracle as O
+
+    threads = min(os.cpu_count() or 1, 64)
+    keys = O.split(O.prng_key(0), BATCH_PER_GPU)
+    O.generate_batch(keys[:256], GRID, AGENTS, threads=threads, want_solved=False)  # warm up
+    t0 = time.perf_counter()
+    for _ in range(sample_batches):
+        O.generate_batch(keys, GRID, AGENTS, threads=threads, want_solved=False)
+    dt = time.perf_counter() - t0
+    boards = sample_batches * BATCH_PER_GPU
+    return {"value": boards / dt, "unit": "boards/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_batches} x {BATCH_PER_GPU} boards 16x16/10 "
+                      f"(keys split(PRNGKey(0),4096)), {dt:.1f} s wall on {threads} threads"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--env-steps", type=int, default=100,
+                    help="env steps of the secondary Connector rollout measurement (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4,
+                    help="batches of 4096 boards timed for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import routing_board_generation_amd as rbg
+    from routing_board_generation_amd import ops, sharding
+
+    rank, local_rank, world = sharding.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with "
+                         "torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path to time")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    rbg._native.lib()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---------------------------------------------------------------- inputs resident in HBM
+    all_keys = rbg.split(rbg.PRNGKey(0, device=dev), BATCH_PER_GPU * world)
+    keys = sharding.shard_keys(all_keys, rank, world)
+    B, m, N = keys.shape[0], GRID, AGENTS
+    out = ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_train=True,
+                           want_state=True, want_iters=True)
+
+    def step():
+        ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_train=True,
+                         want_state=True, want_iters=True, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    # ---------------------------------------------------------------- timed region
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()  # on torch's current stream == the stream the kernel is launched on
+        step()
+        e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+
+    iters = out["iters"]
+    metrics = sharding.all_reduce_metrics({
+        "boards": float(B * args.steps), "iters": float(iters.sum().item()),
+        "max_iters": float(iters.max().item()), "elapsed_s": elapsed}, device=dev)
+    total_elapsed = metrics["elapsed_s"]  # max over ranks
+    value = metrics["boards"] / total_elapsed
+
+    bpb = generator_bytes_per_board(m, N)
+    achieved = B * bpb / (kernel_avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "prw_generate_kernel", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "bytes_per_board": bpb, "boards_per_launch": B,
+                "kernel_avg_ms": kernel_avg_ms, "kernel_p50_ms": kernel_ms[len(kernel_ms) // 2],
+                "note": "latency-bound walk (serial dependent iterations per board): HBM fraction "
+                        "reported for the record; see DESIGN.md"}
+
+    # ---------------------------------------------------------------- secondary: env.step rollout
+    env_step = None
+    if args.env_steps > 0:
+        st, ts = ops.connector_reset(keys, m, N)
+        act = torch.empty((B, N), dtype=torch.int32, device=dev)
+
+        def env_iter(t):
+            ops.random_actions(keys, t, ts["action_mask"], out=act)
+            ops.connector_step(st, act, auto_reset=True, state_out=st, timestep=ts)
+
+        for t in range(10):
+            env_iter(t)
+        sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(args.env_steps)]
+        barrier()
+        t1 = time.perf_counter()
+        for t, (e0, e1) in enumerate(sev):
+            ops.random_actions(keys, 10 + t, ts["action_mask"], out=act)
+            e0.record()
+            ops.connector_step(st, act, auto_reset=True, state_out=st, timestep=ts)
+            e1.record()
+        barrier()
+        env_elapsed = time.perf_counter() - t1
+        k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in sev)
+        k_avg = sum(k_ms) / len(k_ms)
+        em = sharding.all_reduce_metrics({"env_steps": float(B * args.env_steps),
+                                          "elapsed_s": env_elapsed}, device=dev)
+        sb = env_step_bytes(m, N)
+        ach = B * sb / (k_avg * 1e-3) / 1e9
+        env_step = {"metric": "env_steps_per_sec", "value": em["env_steps"] / em["elapsed_s"],
+                    "unit": "env-steps/s", "steps": args.env_steps, "auto_reset": True,
+                    "policy": "rbg_random_actions (masked uniform)",
+                    "roofline": {"bound": "hbm", "kernel": "connector_kernel", "achieved": ach,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "traffic": None, "bytes_per_env_step": sb,
+                                 "kernel_avg_ms": k_avg, "kernel_p50_ms": k_ms[len(k_ms) // 2]}}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        cpu = cpu_baseline(args.cpu_sample)
+
+    if rank == 0:
+        line = {
+            "metric": "boards_per_sec", "value": value, "unit": "boards/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": total_elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "ParallelRandomWalkGenerator 16x16 grid, 10 agents, "
+                                   f"batch {BATCH_PER_GPU} per GPU (BASELINE configs[1])",
+                       "grid_size": m, "num_agents": N, "batch_per_gpu": B,
+                       "global_batch": int(B * world), "keys": "split(PRNGKey(0), global_batch)",
+                       "sharding": f"batch-sharded x{world}, no data-path collective",
+                       "mean_walk_iters": metrics["iters"] / (B * world),
+                       "max_walk_iters": metrics["max_iters"]},
+            "roofline": roofline, "cpu_baseline": cpu, "env_step": env_step,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,11 +99,13 @@ int rbg_split_batch(const uint32_t *keys, int B, int num, uint32_t *out, void *s
  *   (adds `key, _ = split(key)`; key_out = State.key)
  * Outputs: solved_grid (nullable) = generate_board's 3rd result; train_grid (nullable) = the
  * State.grid built at parallel_random_walk_generator.py:63-64 (heads and targets only);
- * start = heads, target = final positions, both agent-major [B][N][2]; key_out (nullable);
+ * start = heads, target = final positions, both agent-major [B][N][2]; position (nullable,
+ * = start) and step_count (nullable, = 0) complete the State of :68-77; key_out (nullable);
  * iters (nullable) = while_loop trip count per board. */
 int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
                      int32_t *solved_grid, int32_t *train_grid, int32_t *start, int32_t *target,
-                     uint32_t *key_out, int32_t *iters, void *stream);
+                     int32_t *position, int32_t *step_count, uint32_t *key_out, int32_t *iters,
+                     void *stream);
 
 /* vmap(UniformRandomGenerator(m, N).__call__)(keys)
  *   routing_board_generation/rl_training/online_generators/uniform_generator.py:70-109 */

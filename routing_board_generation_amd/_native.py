@@ -49,7 +49,7 @@ SIGNATURES = {
     "rbg_split_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rbg_prw_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "rbg_uniform_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rbg_connector_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(State),

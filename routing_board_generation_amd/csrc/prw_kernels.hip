@@ -482,6 +482,8 @@ struct GenArgs {
   int32_t *train_grid;
   int32_t *start;
   int32_t *target;
+  int32_t *position;
+  int32_t *step_count;
   uint32_t *key_out;
   int32_t *iters;
 };
@@ -513,9 +515,11 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
     const size_t o = ((size_t)b * a.N + lane) * 2;
     *reinterpret_cast<int2 *>(&a.start[o]) = make_int2(w.r0, w.c0);
     *reinterpret_cast<int2 *>(&a.target[o]) = make_int2(w.r, w.c);
+    if (a.position) *reinterpret_cast<int2 *>(&a.position[o]) = make_int2(w.r0, w.c0);
   }
   if (lane == 0) {
     if (a.key_out) *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(key.a, key.b);
+    if (a.step_count) a.step_count[b] = 0;
     if (a.iters) a.iters[b] = iters;
   }
 }
@@ -812,6 +816,14 @@ int make_geo(int m, int N, Geo *g) {
   return 0;
 }
 
+// The m % 4 == 0 fast path moves grids with 16-byte loads/stores.
+int check_align(const Geo &g, const void *p0, const void *p1, const void *p2) {
+  if ((g.m & 3) != 0) return 0;
+  const uintptr_t bits = (uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2;
+  if (bits & 15u) return fail(RBG_E_PARAM, "grid buffers must be 16-byte aligned when m % 4 == 0");
+  return 0;
+}
+
 size_t lds_bytes(const Geo &g) {
   return (size_t)kWavesPerBlock * (size_t)((g.words + 3) & ~3) * sizeof(uint32_t);
 }
@@ -848,10 +860,10 @@ int rbg_split(uint32_t key0, uint32_t key1, int num, uint32_t *out, void *stream
 }
 
 int rbg_split_batch(const uint32_t *keys, int B, int num, uint32_t *out, void *stream) {
-  if (!keys || !out) return fail(RBG_E_NULL, "rbg_split_batch: NULL pointer");
   if (B < 0 || num < 0) return fail(RBG_E_SHAPE, "rbg_split_batch: negative size");
   const size_t total = (size_t)B * (size_t)num;
   if (total == 0) return 0;
+  if (!keys || !out) return fail(RBG_E_NULL, "rbg_split_batch: NULL pointer");
   hipLaunchKernelGGL(split_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, keys, B, num, out);
   return check_hip(hipGetLastError(), "rbg_split_batch");
@@ -859,15 +871,17 @@ int rbg_split_batch(const uint32_t *keys, int B, int num, uint32_t *out, void *s
 
 int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
                      int32_t *solved_grid, int32_t *train_grid, int32_t *start, int32_t *target,
-                     uint32_t *key_out, int32_t *iters, void *stream) {
-  if (!keys || !start || !target) return fail(RBG_E_NULL, "rbg_prw_generate: NULL pointer");
+                     int32_t *position, int32_t *step_count, uint32_t *key_out, int32_t *iters,
+                     void *stream) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_prw_generate: B < 0");
   GenArgs a;
   if (int rc = make_geo(m, N, &a.g)) return rc;
-  if (B == 0) return 0;
+  if (B == 0) return 0;  // an empty batch may come with NULL (empty-tensor) pointers
+  if (!keys || !start || !target) return fail(RBG_E_NULL, "rbg_prw_generate: NULL pointer");
+  if (int rc = check_align(a.g, solved_grid, train_grid, nullptr)) return rc;
   a.keys = keys; a.B = B; a.N = N; a.split_first = split_first != 0;
   a.solved_grid = solved_grid; a.train_grid = train_grid; a.start = start; a.target = target;
-  a.key_out = key_out; a.iters = iters;
+  a.position = position; a.step_count = step_count; a.key_out = key_out; a.iters = iters;
   hipLaunchKernelGGL(prw_generate_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
                      dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
   return check_hip(hipGetLastError(), "rbg_prw_generate");
@@ -875,12 +889,13 @@ int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
 
 int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *train_grid,
                          int32_t *start, int32_t *target, uint32_t *key_out, void *stream) {
-  if (!keys || !start || !target) return fail(RBG_E_NULL, "rbg_uniform_generate: NULL pointer");
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_uniform_generate: B < 0");
   UniformArgs a;
   if (int rc = make_geo(m, N, &a.g)) return rc;
   if (2 * N > m * m) return fail(RBG_E_SHAPE, "rbg_uniform_generate: 2N exceeds m*m cells");
   if (B == 0) return 0;
+  if (!keys || !start || !target) return fail(RBG_E_NULL, "rbg_uniform_generate: NULL pointer");
+  if (int rc = check_align(a.g, train_grid, nullptr, nullptr)) return rc;
   a.keys = keys; a.B = B; a.N = N;
   a.train_grid = train_grid; a.start = start; a.target = target; a.key_out = key_out;
   hipLaunchKernelGGL(uniform_generate_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
@@ -896,13 +911,14 @@ static int launch_env(EnvArgs &a, void *stream, const char *what) {
 
 int rbg_connector_reset(const uint32_t *keys, int B, int m, int N, const rbg_state *state,
                         const rbg_timestep *timestep, void *stream) {
-  if (!keys || !timestep) return fail(RBG_E_NULL, "rbg_connector_reset: NULL pointer");
-  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_connector_reset: incomplete state");
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_reset: B < 0");
   EnvArgs a;
   memset(&a, 0, sizeof(a));
   if (int rc = make_geo(m, N, &a.g)) return rc;
   if (B == 0) return 0;
+  if (!keys || !timestep) return fail(RBG_E_NULL, "rbg_connector_reset: NULL pointer");
+  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_connector_reset: incomplete state");
+  if (int rc = check_align(a.g, state->grid, timestep->obs_grid, nullptr)) return rc;
   a.keys = keys; a.B = B; a.N = N; a.out = to_ptrs(state); a.in = a.out;
   a.ts = to_ptrs(timestep); a.mode = 0;
   return launch_env(a, stream, "rbg_connector_reset");
@@ -910,13 +926,14 @@ int rbg_connector_reset(const uint32_t *keys, int B, int m, int N, const rbg_sta
 
 int rbg_connector_observe(int B, int m, int N, const rbg_state *state,
                           const rbg_timestep *timestep, void *stream) {
-  if (!timestep) return fail(RBG_E_NULL, "rbg_connector_observe: NULL timestep");
-  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_connector_observe: incomplete state");
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_observe: B < 0");
   EnvArgs a;
   memset(&a, 0, sizeof(a));
   if (int rc = make_geo(m, N, &a.g)) return rc;
   if (B == 0) return 0;
+  if (!timestep) return fail(RBG_E_NULL, "rbg_connector_observe: NULL timestep");
+  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_connector_observe: incomplete state");
+  if (int rc = check_align(a.g, state->grid, timestep->obs_grid, nullptr)) return rc;
   a.B = B; a.N = N; a.in = to_ptrs(state); a.out = a.in; a.ts = to_ptrs(timestep); a.mode = 1;
   return launch_env(a, stream, "rbg_connector_observe");
 }
@@ -924,15 +941,17 @@ int rbg_connector_observe(int B, int m, int N, const rbg_state *state,
 int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg_state *state_out,
                        const int32_t *action, const rbg_env_params *params,
                        const rbg_timestep *timestep, void *stream) {
-  if (!action || !params || !timestep) return fail(RBG_E_NULL, "rbg_connector_step: NULL pointer");
-  if (!state_complete(state_in) || !state_complete(state_out))
-    return fail(RBG_E_NULL, "rbg_connector_step: incomplete state");
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_step: B < 0");
+  if (!params) return fail(RBG_E_NULL, "rbg_connector_step: NULL params");
   if (params->time_limit < 1) return fail(RBG_E_PARAM, "rbg_connector_step: time_limit < 1");
   EnvArgs a;
   memset(&a, 0, sizeof(a));
   if (int rc = make_geo(m, N, &a.g)) return rc;
   if (B == 0) return 0;
+  if (!action || !timestep) return fail(RBG_E_NULL, "rbg_connector_step: NULL pointer");
+  if (!state_complete(state_in) || !state_complete(state_out))
+    return fail(RBG_E_NULL, "rbg_connector_step: incomplete state");
+  if (int rc = check_align(a.g, state_in->grid, state_out->grid, timestep->obs_grid)) return rc;
   a.B = B; a.N = N; a.in = to_ptrs(state_in); a.out = to_ptrs(state_out); a.action = action;
   a.p = *params; a.ts = to_ptrs(timestep); a.mode = 2;
   return launch_env(a, stream, "rbg_connector_step");
@@ -940,10 +959,10 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
 
 int rbg_random_actions(const uint32_t *keys, int B, int N, uint32_t t, const uint8_t *action_mask,
                        int32_t *action, void *stream) {
-  if (!keys || !action_mask || !action) return fail(RBG_E_NULL, "rbg_random_actions: NULL pointer");
   if (B < 0 || N < 1 || N > kMaxN) return fail(RBG_E_SHAPE, "rbg_random_actions: bad B or N");
   const size_t total = (size_t)B * (size_t)N;
   if (total == 0) return 0;
+  if (!keys || !action_mask || !action) return fail(RBG_E_NULL, "rbg_random_actions: NULL pointer");
   hipLaunchKernelGGL(random_actions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, keys, B, N, t, action_mask, action);
   return check_hip(hipGetLastError(), "rbg_random_actions");

@@ -19,10 +19,10 @@ class ParallelRandomWalkGenerator(Generator):
     def __call__(self, key: torch.Tensor) -> State:
         batched = key.dim() == 2
         keys = key if batched else key[None]
-        B, dev = keys.shape[0], keys.device
         out = ops.prw_generate(keys.contiguous(), self.grid_size, self.num_agents,
-                               split_first=True, want_solved=False, want_train=True)
+                               split_first=True, want_solved=False, want_train=True,
+                               want_state=True)
         st = {"grid": out["train_grid"], "start": out["start"], "target": out["target"],
-              "position": out["start"].clone(), "key": out["key_out"],
-              "step_count": torch.zeros((B,), dtype=torch.int32, device=dev)}
+              "position": out["position"], "key": out["key_out"],
+              "step_count": out["step_count"]}
         return state_from_bufs(st, batched)

@@ -118,8 +118,10 @@ def split_batch(keys: torch.Tensor, num: int) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------- generators
 def prw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool, want_solved: bool = True,
-                 want_train: bool = True, want_iters: bool = False, out: Optional[dict] = None):
-    """Returns dict(solved_grid?, train_grid?, start, target, key_out, iters?)."""
+                 want_train: bool = True, want_iters: bool = False, want_state: bool = False,
+                 out: Optional[dict] = None):
+    """Returns dict(solved_grid?, train_grid?, start, target, position?, step_count?, key_out,
+    iters?); `out` may carry preallocated buffers under the same names."""
     keys = check_keys(keys)
     B, dev = keys.shape[0], keys.device
     i32 = dict(dtype=torch.int32, device=dev)
@@ -136,6 +138,14 @@ def prw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool, want_sol
         o["key_out"] = torch.empty((B, 2), dtype=torch.uint32, device=dev)
     if want_iters and "iters" not in o:
         o["iters"] = torch.empty((B,), **i32)
+    if want_state and "position" not in o:
+        o["position"] = torch.empty((B, N, 2), **i32)
+    if want_state and "step_count" not in o:
+        o["step_count"] = torch.empty((B,), **i32)
+    if "position" in o:
+        _check(o["position"], torch.int32, (B, N, 2), "position")
+    if "step_count" in o:
+        _check(o["step_count"], torch.int32, (B,), "step_count")
     for f in ("solved_grid", "train_grid"):
         if f in o:
             _check(o[f], torch.int32, (B, m, m), f)
@@ -145,7 +155,8 @@ def prw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool, want_sol
     nat.check(nat.lib().rbg_prw_generate(
         keys.data_ptr(), B, m, N, int(split_first), _ptr(o.get("solved_grid")),
         _ptr(o.get("train_grid")), o["start"].data_ptr(), o["target"].data_ptr(),
-        o["key_out"].data_ptr(), _ptr(o.get("iters")), _stream(dev)), "rbg_prw_generate")
+        _ptr(o.get("position")), _ptr(o.get("step_count")), o["key_out"].data_ptr(),
+        _ptr(o.get("iters")), _stream(dev)), "rbg_prw_generate")
     return o
 
 

@@ -46,13 +46,13 @@ def test_struct_layouts_match_header(native):
 
 def test_argument_errors_do_not_need_a_gpu(native):
     lib = native.lib()
-    assert lib.rbg_prw_generate(None, 1, 16, 10, 1, None, None, None, None, None, None, None) == -1
+    assert lib.rbg_prw_generate(None, 1, 16, 10, 1, None, None, None, None, None, None, None, None, None) == -1
     assert b"NULL" in lib.rbg_last_error()
     one = C.c_void_p(16)  # never dereferenced: shape checks come first
-    assert lib.rbg_prw_generate(one, 1, 41, 10, 1, None, None, one, one, None, None, None) == -2
-    assert lib.rbg_prw_generate(one, 1, 16, 65, 1, None, None, one, one, None, None, None) == -2
-    assert lib.rbg_prw_generate(one, 1, 3, 10, 1, None, None, one, one, None, None, None) == -2
-    assert lib.rbg_prw_generate(one, -1, 16, 10, 1, None, None, one, one, None, None, None) == -2
+    assert lib.rbg_prw_generate(one, 1, 41, 10, 1, None, None, one, one, None, None, None, None, None) == -2
+    assert lib.rbg_prw_generate(one, 1, 16, 65, 1, None, None, one, one, None, None, None, None, None) == -2
+    assert lib.rbg_prw_generate(one, 1, 3, 10, 1, None, None, one, one, None, None, None, None, None) == -2
+    assert lib.rbg_prw_generate(one, -1, 16, 10, 1, None, None, one, one, None, None, None, None, None) == -2
     assert lib.rbg_uniform_generate(one, 1, 4, 9, None, one, one, None, None) == -2
     assert lib.rbg_split(0, 0, 4, None, None) == -1
     with pytest.raises(native.NativeLibraryError):
