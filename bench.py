@@ -55,7 +55,9 @@ def cpu_baseline(sample_batches: int):
 
     from oracle import oracle as O
 
-    threads = min(os.cpu_count() or 1, 64)
+    threads = min(len(os.sched_getaffinity(0)) or 1, 64)
+    if sample_batches < 0:
+        sample_batches = max(4, threads // 4)
     keys = O.split(O.prng_key(0), BATCH_PER_GPU)
     O.generate_batch(keys[:256], GRID, AGENTS, threads=threads, want_solved=False)  # warm up
     t0 = time.perf_counter()
@@ -75,8 +77,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--env-steps", type=int, default=100,
                     help="env steps of the secondary Connector rollout measurement (0 = skip)")
-    ap.add_argument("--cpu-sample", type=int, default=4,
-                    help="batches of 4096 boards timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="batches of 4096 boards timed for cpu_baseline (0 = skip; default: "
+                         "threads/4, i.e. ~20 core-seconds of CPU work)")
     args = ap.parse_args()
 
     import torch
@@ -182,7 +185,7 @@ def main() -> None:
                                  "kernel_avg_ms": k_avg, "kernel_p50_ms": k_ms[len(k_ms) // 2]}}
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
         cpu = cpu_baseline(args.cpu_sample)
 
     if rank == 0:

@@ -212,21 +212,74 @@ struct Walker {
   int P;       // padded index of the head
 };
 
+constexpr int kPrngScratchWords = 2 * kMaxN;  // split(key, N) words of one iteration
+
+// One round of the lane-parallel PRNG pipeline.  A walk iteration consumes, per board,
+//   keys = split(k_t, N)  (N Threefry blocks),  u_i = uniform(keys[i])  (N blocks),
+//   k_{t+1} = split(k_t)[1]  (2 blocks)
+// none of which depends on the board.  Instead of 5 dependent blocks per lane the 2N + 2 blocks
+// of one round are spread over the lanes of the wave as "virtual slots" and ONE Threefry
+// evaluation per 64 slots serves three pipeline stages at once:
+//   slot s < N          uniform(keys(t+1)[s])            -> u_s(t+1), lands in agent lane s
+//   slot N + j, j < N   block j of split(k_{t+2}, N)     -> W (LDS), read by the next round
+//   slot 2N + x, x < 2  block x of split(k_{t+2})        -> k_{t+3} (wave-uniform, via readlane)
+// so the randomness of iteration t+1 is finished while iteration t waits on its LDS stencil.
+__device__ __forceinline__ float prng_round(uint32_t *W, int N, int lane, Key2 &kcur) {
+  const int twoN = 2 * N;
+  float u = 0.0f;
+  uint32_t nk0 = 0u, nk1 = 0u;
+  for (int base = 0; base < twoN + 2; base += kWaveSize) {
+    const int s = base + lane;
+    const bool r_uni = s < N;
+    const bool r_split = !r_uni && s < twoN;
+    uint32_t ka = kcur.a, kb = kcur.b;
+    uint32_t c0 = (uint32_t)(s - twoN), c1 = (uint32_t)(s - twoN + 2);  // split(k): (x, x + 2)
+    if (r_uni) {
+      const uint2 kk = *reinterpret_cast<const uint2 *>(&W[2 * s]);  // child s of split(k, N)
+      ka = kk.x;
+      kb = kk.y;
+      c0 = c1 = 0u;  // random_bits(key, 1): counters (0, pad 0)
+    } else if (r_split) {
+      c0 = (uint32_t)(s - N);  // block j hashes (j, N + j); out = y0-half ++ y1-half
+      c1 = (uint32_t)s;
+    }
+    uint32_t y0, y1;
+    threefry(ka, kb, c0, c1, y0, y1);
+    if (r_uni) u = __fsub_rn(__uint_as_float((y0 >> 9) | 0x3F800000u), 1.0f);
+    if (r_split) {
+      W[s - N] = y0;
+      W[s] = y1;
+    }
+    if (base == (twoN & ~(kWaveSize - 1))) {  // wave-uniform: the call that holds slots 2N, 2N+1
+      nk0 = __builtin_amdgcn_readlane(y1, twoN & (kWaveSize - 1));
+      nk1 = __builtin_amdgcn_readlane(y1, (twoN & (kWaveSize - 1)) + 1);
+    }
+  }
+  wave_lds_fence();
+  kcur.a = nk0;
+  kcur.b = nk1;
+  return u;
+}
+
 // Runs generate_board(key) on `board` (LDS, padded).  On return the board holds the solved grid
 // with the head/target encodings of :435-447 applied; lanes i < N hold agent i's start / final
 // position.  Returns the while_loop trip count.
-__device__ __forceinline__ int prw_walk(uint32_t *board, const Geo &g, int N, Key2 key, int lane,
-                                        Walker &w) {
+//
+// During the walk every cell of wire i holds the single value 3i+1: the walk never needs to tell
+// a head from a path cell (availability only asks "empty?" and "own wire?"), and the value is
+// still monotone in the agent id, which is all the max-join needs.  Heads and targets are
+// written once at the end from the positions kept in registers.
+__device__ __forceinline__ int prw_walk(uint32_t *board, uint32_t *W, const Geo &g, int N,
+                                        Key2 key, int lane, Walker &w) {
   const Key2 kB = split2(key, 0);   // key, step_key = split(key)   (:73)
-  Key2 k = split2(key, 1);
+  Key2 kcur = split2(key, 1);       // k_0
   const bool is_agent = lane < N;
 
   // _initialise_agents (:147-186): N distinct cells = first N of the shuffled arange(m*m)
   int sel0, sel1;
   shuffle_prefix(board, g, kB, N, lane, sel0, sel1);
   board_clear(board, g, lane);
-  const uint32_t head = 3u * (uint32_t)lane + 2u;  // get_position(id)
-  const uint32_t path = head - 1u;                 // get_path(id)
+  const uint32_t wire = 3u * (uint32_t)lane + 1u;
   w.r0 = w.c0 = w.r = w.c = 0;
   w.P = pad_index(g, 0, 0);
   if (is_agent) {
@@ -235,9 +288,13 @@ __device__ __forceinline__ int prw_walk(uint32_t *board, const Geo &g, int N, Ke
     w.r = w.r0;
     w.c = w.c0;
     w.P = pad_index(g, w.r, w.c);
-    board[w.P] = head;
+    board[w.P] = wire;
   }
   wave_lds_fence();
+
+  // pipeline prologue: W <- split(k_0, N), kcur <- k_1; then u <- u(0), W <- split(k_1, N), ...
+  (void)prng_round(W, N, lane, kcur);
+  float u = prng_round(W, N, lane, kcur);
 
   const int S = g.S;
   int iters = 0;
@@ -253,14 +310,15 @@ __device__ __forceinline__ int prw_walk(uint32_t *board, const Geo &g, int N, Ke
     const uint32_t ll = board[P - 2], rr = board[P + 2];
     const uint32_t ul = board[P - S - 1], ur = board[P - S + 1];
     const uint32_t dl = board[P + S - 1], dr = board[P + S + 1];
-#define RBG_OWN(v) ((uint32_t)((v) - path) < 3u)
-    const bool own_ul = RBG_OWN(ul), own_ur = RBG_OWN(ur), own_dl = RBG_OWN(dl),
-               own_dr = RBG_OWN(dr);
-    const bool a_up = is_agent && vu == 0u && !(RBG_OWN(uu) || own_ul || own_ur);
-    const bool a_dn = is_agent && vd == 0u && !(RBG_OWN(dd) || own_dl || own_dr);
-    const bool a_lf = is_agent && vl == 0u && !(RBG_OWN(ll) || own_ul || own_dl);
-    const bool a_rt = is_agent && vr == 0u && !(RBG_OWN(rr) || own_ur || own_dr);
-#undef RBG_OWN
+
+    // randomness of the NEXT iteration: independent of the board, overlaps the LDS latency above
+    const float u_next = prng_round(W, N, lane, kcur);
+
+    const bool own_ul = ul == wire, own_ur = ur == wire, own_dl = dl == wire, own_dr = dr == wire;
+    const bool a_up = is_agent && vu == 0u && !(uu == wire || own_ul || own_ur);
+    const bool a_dn = is_agent && vd == 0u && !(dd == wire || own_dl || own_dr);
+    const bool a_lf = is_agent && vl == 0u && !(ll == wire || own_ul || own_dl);
+    const bool a_rt = is_agent && vr == 0u && !(rr == wire || own_ur || own_dr);
     const int c1 = (int)a_up, c2 = c1 + (int)a_dn, c3 = c2 + (int)a_lf, c4 = c3 + (int)a_rt;
 
     // ---- _continue_stepping (:192-203): stop when no agent has an available cell ----------
@@ -268,8 +326,6 @@ __device__ __forceinline__ int prw_walk(uint32_t *board, const Geo &g, int N, Ke
 
     // ---- _select_action (:205-230): keys = split(key, N); choice(p = available) -----------
     // choice: cum = cumsum(p); r = cum[-1] * (1 - uniform(key_i)); first index with cum >= r.
-    const Key2 ki = split_child(k, (uint32_t)(is_agent ? lane : 0), (uint32_t)N);
-    const float u = uniform01(ki);
     const float rsel = __fmul_rn((float)c4, __fsub_rn(1.0f, u));
     int dir = 3;
     if ((float)c3 >= rsel) dir = 2;
@@ -280,23 +336,20 @@ __device__ __forceinline__ int prw_walk(uint32_t *board, const Geo &g, int N, Ke
     const int Q = P + dP;
 
     // ---- _step_agents (:101-145): contested cell -> highest id wins, losers stay ----------
-    if (mover) atomicMax(&board[Q], head);
+    if (mover) atomicMax(&board[Q], wire);
     wave_lds_fence();
-    if (mover && board[Q] == head) {
-      board[P] = path;
+    if (mover && board[Q] == wire) {
       w.P = Q;
       w.r += dir == 0 ? -1 : dir == 1 ? 1 : 0;
       w.c += dir == 2 ? -1 : dir == 3 ? 1 : 0;
     }
-    wave_lds_fence();
-
-    k = split2(k, 1);  // _step (:98): key, next_key = split(key); carry next_key
+    u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
   }
 
   // update_solved_board_with_head_target_encodings (:435-447): heads first, then targets
-  if (is_agent) board[pad_index(g, w.r0, w.c0)] = head;
+  if (is_agent) board[pad_index(g, w.r0, w.c0)] = wire + 1u;  // get_position(id)
   wave_lds_fence();
-  if (is_agent) board[w.P] = head + 1u;  // get_target(id); wins when the agent never moved
+  if (is_agent) board[w.P] = wire + 2u;  // get_target(id); wins when the agent never moved
   wave_lds_fence();
   return iters;
 }
@@ -490,14 +543,19 @@ struct GenArgs {
 
 extern __shared__ __attribute__((aligned(16))) uint32_t g_lds[];
 
+// per-wave LDS slab: padded board (16-B aligned) followed by the PRNG pipeline's W scratch
 __device__ __forceinline__ int wave_board_words(const Geo &g) { return (g.words + 3) & ~3; }
+__device__ __forceinline__ int wave_slab_words(const Geo &g) {
+  return wave_board_words(g) + kPrngScratchWords;
+}
 
 __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;
   if (b >= a.B) return;  // wave-uniform; waves of a block never synchronise with each other
-  uint32_t *board = g_lds + wib * wave_board_words(a.g);
+  uint32_t *board = g_lds + wib * wave_slab_words(a.g);
+  uint32_t *W = board + wave_board_words(a.g);
   const Geo g = a.g;
 
   Key2 key;
@@ -506,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   if (a.split_first) key = split2(key, 0);  // key, pos_key = split(key)  (generator :52)
 
   Walker w;
-  const int iters = prw_walk(board, g, a.N, key, lane, w);
+  const int iters = prw_walk(board, W, g, a.N, key, lane, w);
 
   const size_t gofs = (size_t)b * g.n;
   if (a.solved_grid) store_grid<false>(board, g, lane, a.solved_grid + gofs);
@@ -540,7 +598,8 @@ __global__ __launch_bounds__(kBlock) void uniform_generate_kernel(UniformArgs a)
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;
   if (b >= a.B) return;
-  uint32_t *board = g_lds + wib * wave_board_words(a.g);
+  uint32_t *board = g_lds + wib * wave_slab_words(a.g);
+  uint32_t *W = board + wave_board_words(a.g);
   const Geo g = a.g;
   Key2 key;
   key.a = a.keys[2 * (size_t)b];
@@ -606,12 +665,12 @@ __device__ __forceinline__ void write_extras(const uint32_t *board, const Geo &g
 
 // Generator -> State: runs the walk for `key_in` (the generator's argument), leaves the training
 // grid in LDS, fills agent registers, writes the State to HBM.
-__device__ __forceinline__ void generate_state(uint32_t *board, const Geo &g, int N, int b,
+__device__ __forceinline__ void generate_state(uint32_t *board, uint32_t *W, const Geo &g, int N, int b,
                                                int lane, Key2 key_in, const StatePtrs &out,
                                                AgentRegs &ag) {
   const Key2 key = split2(key_in, 0);
   Walker w;
-  prw_walk(board, g, N, key, lane, w);
+  prw_walk(board, W, g, N, key, lane, w);
   board_to_training(board, g, lane);
   ag.r0 = w.r0; ag.c0 = w.c0;
   ag.tr = w.r;  ag.tc = w.c;
@@ -629,7 +688,8 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;
   if (b >= a.B) return;
-  uint32_t *board = g_lds + wib * wave_board_words(a.g);
+  uint32_t *board = g_lds + wib * wave_slab_words(a.g);
+  uint32_t *W = board + wave_board_words(a.g);
   const Geo g = a.g;
   const int N = a.N;
   const bool is_agent = lane < N;
@@ -639,7 +699,7 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     Key2 kin;
     kin.a = a.keys[2 * (size_t)b];
     kin.b = a.keys[2 * (size_t)b + 1];
-    generate_state(board, g, N, b, lane, kin, a.out, ag);
+    generate_state(board, W, g, N, b, lane, kin, a.out, ag);
     write_observation(board, g, N, b, lane, ag, 0, a.ts);
     write_extras(board, g, N, b, lane, ag, a.ts);
     if (is_agent) {
@@ -721,7 +781,7 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     Key2 sk;
     sk.a = a.in.key[2 * (size_t)b];
     sk.b = a.in.key[2 * (size_t)b + 1];
-    generate_state(board, g, N, b, lane, split2(sk, 0), a.out, ag);
+    generate_state(board, W, g, N, b, lane, split2(sk, 0), a.out, ag);
     write_observation(board, g, N, b, lane, ag, 0, a.ts);
     return;
   }
@@ -825,7 +885,8 @@ int check_align(const Geo &g, const void *p0, const void *p1, const void *p2) {
 }
 
 size_t lds_bytes(const Geo &g) {
-  return (size_t)kWavesPerBlock * (size_t)((g.words + 3) & ~3) * sizeof(uint32_t);
+  return (size_t)kWavesPerBlock * (size_t)(((g.words + 3) & ~3) + kPrngScratchWords) *
+         sizeof(uint32_t);
 }
 
 StatePtrs to_ptrs(const rbg_state *s) {
