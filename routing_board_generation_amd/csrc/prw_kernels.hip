@@ -224,30 +224,32 @@ constexpr int kPrngScratchWords = 2 * kMaxN;  // split(key, N) words of one iter
 //   slot N + j, j < N   block j of split(k_{t+2}, N)     -> W (LDS), read by the next round
 //   slot 2N + x, x < 2  block x of split(k_{t+2})        -> k_{t+3} (wave-uniform, via readlane)
 // so the randomness of iteration t+1 is finished while iteration t waits on its LDS stencil.
+// kSingle: 2N + 2 <= 64, all slots fit one call (no loop; the Threefry block is straight-line
+// code the scheduler can interleave with the stencil).
+template <bool kSingle>
 __device__ __forceinline__ float prng_round(uint32_t *W, int N, int lane, Key2 &kcur) {
   const int twoN = 2 * N;
   float u = 0.0f;
   uint32_t nk0 = 0u, nk1 = 0u;
-  for (int base = 0; base < twoN + 2; base += kWaveSize) {
+  const int last_base = kSingle ? 0 : ((twoN + 1) & ~(kWaveSize - 1));
+#pragma unroll 1
+  for (int base = 0; base <= last_base; base += kWaveSize) {
     const int s = base + lane;
     const bool r_uni = s < N;
     const bool r_split = !r_uni && s < twoN;
-    uint32_t ka = kcur.a, kb = kcur.b;
-    uint32_t c0 = (uint32_t)(s - twoN), c1 = (uint32_t)(s - twoN + 2);  // split(k): (x, x + 2)
-    if (r_uni) {
-      const uint2 kk = *reinterpret_cast<const uint2 *>(&W[2 * s]);  // child s of split(k, N)
-      ka = kk.x;
-      kb = kk.y;
-      c0 = c1 = 0u;  // random_bits(key, 1): counters (0, pad 0)
-    } else if (r_split) {
-      c0 = (uint32_t)(s - N);  // block j hashes (j, N + j); out = y0-half ++ y1-half
-      c1 = (uint32_t)s;
-    }
+    // child s of split(k, N); the load is unconditional (lane-clamped index) so that the key
+    // stays a VALUE select -- a pointer select here turns into a flat load through scratch
+    const uint2 kk = *reinterpret_cast<const uint2 *>(&W[r_uni ? 2 * s : 0]);
+    const uint32_t ka = r_uni ? kk.x : kcur.a;
+    const uint32_t kb = r_uni ? kk.y : kcur.b;
+    // counters: uniform (0, pad 0) | split block j = s - N: (j, N + j) | split(k) block x: (x, x+2)
+    const uint32_t c0 = r_uni ? 0u : r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
+    const uint32_t c1 = r_uni ? 0u : r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
     uint32_t y0, y1;
     threefry(ka, kb, c0, c1, y0, y1);
     if (r_uni) u = __fsub_rn(__uint_as_float((y0 >> 9) | 0x3F800000u), 1.0f);
     if (r_split) {
-      W[s - N] = y0;
+      W[s - N] = y0;  // out = y0-half ++ y1-half
       W[s] = y1;
     }
     if (base == (twoN & ~(kWaveSize - 1))) {  // wave-uniform: the call that holds slots 2N, 2N+1
@@ -269,8 +271,9 @@ __device__ __forceinline__ float prng_round(uint32_t *W, int N, int lane, Key2 &
 // a head from a path cell (availability only asks "empty?" and "own wire?"), and the value is
 // still monotone in the agent id, which is all the max-join needs.  Heads and targets are
 // written once at the end from the positions kept in registers.
-__device__ __forceinline__ int prw_walk(uint32_t *board, uint32_t *W, const Geo &g, int N,
-                                        Key2 key, int lane, Walker &w) {
+template <bool kSingle>
+__device__ __forceinline__ int prw_walk_impl(uint32_t *board, uint32_t *W, const Geo &g, int N,
+                                             Key2 key, int lane, Walker &w) {
   const Key2 kB = split2(key, 0);   // key, step_key = split(key)   (:73)
   Key2 kcur = split2(key, 1);       // k_0
   const bool is_agent = lane < N;
@@ -293,14 +296,19 @@ __device__ __forceinline__ int prw_walk(uint32_t *board, uint32_t *W, const Geo 
   wave_lds_fence();
 
   // pipeline prologue: W <- split(k_0, N), kcur <- k_1; then u <- u(0), W <- split(k_1, N), ...
-  (void)prng_round(W, N, lane, kcur);
-  float u = prng_round(W, N, lane, kcur);
+  (void)prng_round<kSingle>(W, N, lane, kcur);
+  float u = prng_round<kSingle>(W, N, lane, kcur);
 
   const int S = g.S;
   int iters = 0;
   // Every iteration that runs moves at least the highest-id mover into an empty cell, so the
   // loop ends after at most n - N trips; the explicit bound keeps a faulty board from spinning.
-  for (; iters < g.n; ++iters) {
+#ifdef RBG_PROBE_MAX_ITERS  // developer probe builds only (tools/probe_walk.py)
+  const int max_iters = g.n < RBG_PROBE_MAX_ITERS ? g.n : RBG_PROBE_MAX_ITERS;
+#else
+  const int max_iters = g.n;
+#endif
+  for (; iters < max_iters; ++iters) {
     // ---- _available_cells for [up, down, left, right] (:293-374) -------------------------
     // candidate q is available iff it is empty and touches no cell of this wire other than the
     // head itself ("doubling back" counts the head once, so the other three must be foreign).
@@ -312,7 +320,7 @@ __device__ __forceinline__ int prw_walk(uint32_t *board, uint32_t *W, const Geo 
     const uint32_t dl = board[P + S - 1], dr = board[P + S + 1];
 
     // randomness of the NEXT iteration: independent of the board, overlaps the LDS latency above
-    const float u_next = prng_round(W, N, lane, kcur);
+    const float u_next = prng_round<kSingle>(W, N, lane, kcur);
 
     const bool own_ul = ul == wire, own_ur = ur == wire, own_dl = dl == wire, own_dr = dr == wire;
     const bool a_up = is_agent && vu == 0u && !(uu == wire || own_ul || own_ur);
@@ -352,6 +360,12 @@ __device__ __forceinline__ int prw_walk(uint32_t *board, uint32_t *W, const Geo 
   if (is_agent) board[w.P] = wire + 2u;  // get_target(id); wins when the agent never moved
   wave_lds_fence();
   return iters;
+}
+
+__device__ __forceinline__ int prw_walk(uint32_t *board, uint32_t *W, const Geo &g, int N,
+                                        Key2 key, int lane, Walker &w) {
+  if (2 * N + 2 <= kWaveSize) return prw_walk_impl<true>(board, W, g, N, key, lane, w);
+  return prw_walk_impl<false>(board, W, g, N, key, lane, w);
 }
 
 // ---------------------------------------------------------------------------------------------
