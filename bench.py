@@ -118,18 +118,20 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     # ---------------------------------------------------------------- timed region
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)]
+    # ONE HIP-event pair brackets the K back-to-back launches (on torch's current stream, the
+    # stream the kernel is launched on): a pair per launch costs ~12 us of event latency on this
+    # stack, comparable to the kernel itself.  Average launch duration = event span / K; it
+    # includes the ~1-2 us dependent-launch gap, so it can only overstate the kernel time.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()  # on torch's current stream == the stream the kernel is launched on
+    ev0.record()
+    for _ in range(args.steps):
         step()
-        e1.record()
+    ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    kernel_avg_ms = ev0.elapsed_time(ev1) / args.steps
 
     iters = out["iters"]
     metrics = sharding.all_reduce_metrics({
@@ -143,7 +145,7 @@ def main() -> None:
     roofline = {"bound": "hbm", "kernel": "prw_generate_kernel", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "bytes_per_board": bpb, "boards_per_launch": B,
-                "kernel_avg_ms": kernel_avg_ms, "kernel_p50_ms": kernel_ms[len(kernel_ms) // 2],
+                "kernel_avg_ms": kernel_avg_ms,
                 "note": "latency-bound walk (serial dependent iterations per board): HBM fraction "
                         "reported for the record; see DESIGN.md"}
 
@@ -159,19 +161,16 @@ def main() -> None:
 
         for t in range(10):
             env_iter(t)
-        sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(args.env_steps)]
+        se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t1 = time.perf_counter()
-        for t, (e0, e1) in enumerate(sev):
-            ops.random_actions(keys, 10 + t, ts["action_mask"], out=act)
-            e0.record()
-            ops.connector_step(st, act, auto_reset=True, state_out=st, timestep=ts)
-            e1.record()
+        se0.record()
+        for t in range(args.env_steps):
+            env_iter(10 + t)
+        se1.record()
         barrier()
         env_elapsed = time.perf_counter() - t1
-        k_ms = sorted(e0.elapsed_time(e1) for e0, e1 in sev)
-        k_avg = sum(k_ms) / len(k_ms)
+        k_avg = se0.elapsed_time(se1) / args.env_steps  # policy + step kernels of one env step
         em = sharding.all_reduce_metrics({"env_steps": float(B * args.env_steps),
                                           "elapsed_s": env_elapsed}, device=dev)
         sb = env_step_bytes(m, N)
@@ -182,7 +181,9 @@ def main() -> None:
                     "roofline": {"bound": "hbm", "kernel": "connector_kernel", "achieved": ach,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "traffic": None, "bytes_per_env_step": sb,
-                                 "kernel_avg_ms": k_avg, "kernel_p50_ms": k_ms[len(k_ms) // 2]}}
+                                 "kernel_avg_ms": k_avg,
+                                 "note": "duration of one env step = random_actions_kernel + "
+                                         "connector_kernel (fused auto-reset walks included)"}}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample != 0:

@@ -145,6 +145,7 @@ struct Geo {
                 // serve as the right wall of the previous row)
   int words;    // (m + 4) * S: 2 wall rows above and below
   uint32_t magic;  // ceil(2^20 / m): idx / m == (idx * magic) >> 20 for idx * m < 2^20
+  uint32_t thr;    // shuffle_prefix candidate threshold for this launch's count (0 = slow path)
 };
 
 __device__ __forceinline__ int pad_index(const Geo &g, int r, int c) {
@@ -168,12 +169,18 @@ __device__ __forceinline__ void board_clear(uint32_t *board, const Geo &g, int l
 // ---------------------------------------------------------------------------------------------
 // First `count` entries of jax's one-round _shuffle of arange(n):
 //   key, sub = split(key); sort_keys = random_bits(sub, n); stable sort -> ascending
-//   (sort_key, index).  Selection by `count` wave-wide min-reductions instead of a full sort.
-// Lane l receives entry l in sel0 and entry 64 + l in sel1.  Uses board[0..n) as scratch.
+//   (sort_key, index).
+// No full sort: the first `count` entries are the `count` smallest (sort_key, index) pairs.
+//   fast path  a threshold `thr` (host-computed so that ~3*count keys fall below it) filters the
+//              candidates, a ballot/popcount prefix compacts them one per lane, and every lane
+//              ranks its candidate against the others through v_readlane -- exact whenever
+//              count <= #candidates <= 64;
+//   slow path  otherwise (rare, or count > 32): `count` wave-wide min-reductions.
+// Lane l receives entry l in sel0 and entry 64 + l in sel1.  `scratch` needs n words, `aux` 64.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void shuffle_prefix(uint32_t *scratch, const Geo &g, Key2 key,
-                                               int count, int lane, int &sel0, int &sel1) {
-  const Key2 sub = split2(key, 1);
+__device__ __forceinline__ void shuffle_prefix(uint32_t *scratch, uint32_t *aux, const Geo &g,
+                                               Key2 sub, int count, uint32_t thr, int lane,
+                                               int &sel0, int &sel1) {
   const uint32_t n = (uint32_t)g.n;
   const uint32_t half = (n + 1u) >> 1;
   for (uint32_t j = lane; j < half; j += kWaveSize) {
@@ -184,9 +191,49 @@ __device__ __forceinline__ void shuffle_prefix(uint32_t *scratch, const Geo &g, 
     if (has_hi) scratch[half + j] = y1;
   }
   wave_lds_fence();
+  sel0 = sel1 = -1;
+
+  if (thr != 0u) {
+    // ---- compact the candidates (key < thr) into lanes, in index order ----------------------
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t my_key = 0xFFFFFFFFu, my_idx = 0xFFFFFFFFu;
+    int total = 0;
+    for (uint32_t base = 0; base < n; base += kWaveSize) {
+      const uint32_t j = base + lane;
+      const uint32_t key = j < n ? scratch[j] : 0xFFFFFFFFu;
+      const bool flag = j < n && key < thr;
+      const uint64_t mask = __ballot(flag);
+      const int pos = total + __popcll(mask & lt_mask);
+      if (flag && pos < kWaveSize) {
+        aux[pos] = j;  // the key is re-read below: one word per candidate keeps aux at 64 words
+      }
+      total += __popcll(mask);
+    }
+    wave_lds_fence();
+    if (total >= count && total <= kWaveSize) {
+      if (lane < total) {
+        my_idx = aux[lane];
+        my_key = scratch[my_idx];
+      }
+      const uint64_t mine = ((uint64_t)my_key << 32) | my_idx;
+      int rank = 0;
+      for (int c = 0; c < total; ++c) {
+        const uint32_t ck = __builtin_amdgcn_readlane(my_key, c);
+        const uint32_t ci = __builtin_amdgcn_readlane(my_idx, c);
+        rank += (int)((((uint64_t)ck << 32) | ci) < mine);
+      }
+      wave_lds_fence();
+      if (lane < total) aux[rank] = my_idx;  // ranks of distinct pairs are a permutation
+      wave_lds_fence();
+      if (lane < count) sel0 = (int)aux[lane];
+      wave_lds_fence();
+      return;
+    }
+  }
+
+  // ---- slow path: one wave-wide 64-bit min per entry ------------------------------------------
   uint64_t prev = 0;
   bool have_prev = false;
-  sel0 = sel1 = -1;
   for (int round = 0; round < count; ++round) {
     uint64_t best = ~0ull;
     for (uint32_t j = lane; j < n; j += kWaveSize) {
@@ -203,6 +250,18 @@ __device__ __forceinline__ void shuffle_prefix(uint32_t *scratch, const Geo &g, 
   wave_lds_fence();
 }
 
+// split(key) with the two Threefry blocks in lanes 0 and 1 of ONE evaluation:
+// children (y0[0], y0[1]) and (y1[0], y1[1]) of blocks (0, 2) and (1, 3).
+__device__ __forceinline__ void split2_lanes(Key2 k, int lane, Key2 &child0, Key2 &child1) {
+  const uint32_t x = (uint32_t)(lane & 1);
+  uint32_t y0, y1;
+  threefry(k.a, k.b, x, x + 2u, y0, y1);
+  child0.a = __builtin_amdgcn_readlane(y0, 0);
+  child0.b = __builtin_amdgcn_readlane(y0, 1);
+  child1.a = __builtin_amdgcn_readlane(y1, 0);
+  child1.b = __builtin_amdgcn_readlane(y1, 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The random walk (JAXI/parallel_random_walk.py:60-145, 192-230, 262-374)
 // ---------------------------------------------------------------------------------------------
@@ -212,7 +271,8 @@ struct Walker {
   int P;       // padded index of the head
 };
 
-constexpr int kPrngScratchWords = 2 * kMaxN;  // split(key, N) words of one iteration
+constexpr int kPrngDumpSlot = 2 * kMaxN;          // where non-split lanes park their stores
+constexpr int kPrngScratchWords = 2 * kMaxN + 4;  // split(key, N) words of one iteration + dump
 
 // One round of the lane-parallel PRNG pipeline.  A walk iteration consumes, per board,
 //   keys = split(k_t, N)  (N Threefry blocks),  u_i = uniform(keys[i])  (N blocks),
@@ -248,10 +308,9 @@ __device__ __forceinline__ float prng_round(uint32_t *W, int N, int lane, Key2 &
     uint32_t y0, y1;
     threefry(ka, kb, c0, c1, y0, y1);
     if (r_uni) u = __fsub_rn(__uint_as_float((y0 >> 9) | 0x3F800000u), 1.0f);
-    if (r_split) {
-      W[s - N] = y0;  // out = y0-half ++ y1-half
-      W[s] = y1;
-    }
+    // out = y0-half ++ y1-half; other roles store to a dump slot (branch-free)
+    W[r_split ? s - N : kPrngDumpSlot] = y0;
+    W[r_split ? s : kPrngDumpSlot + 1] = y1;
     if (base == (twoN & ~(kWaveSize - 1))) {  // wave-uniform: the call that holds slots 2N, 2N+1
       nk0 = __builtin_amdgcn_readlane(y1, twoN & (kWaveSize - 1));
       nk1 = __builtin_amdgcn_readlane(y1, (twoN & (kWaveSize - 1)) + 1);
@@ -274,13 +333,19 @@ __device__ __forceinline__ float prng_round(uint32_t *W, int N, int lane, Key2 &
 template <bool kSingle>
 __device__ __forceinline__ int prw_walk_impl(uint32_t *board, uint32_t *W, const Geo &g, int N,
                                              Key2 key, int lane, Walker &w) {
-  const Key2 kB = split2(key, 0);   // key, step_key = split(key)   (:73)
-  Key2 kcur = split2(key, 1);       // k_0
+  Key2 kB, kcur, unused, sub;
+  split2_lanes(key, lane, kB, kcur);  // key, step_key = split(key)   (:73); kcur = k_0
   const bool is_agent = lane < N;
 
-  // _initialise_agents (:147-186): N distinct cells = first N of the shuffled arange(m*m)
+  // _initialise_agents (:147-186): N distinct cells = first N of the shuffled arange(m*m);
+  // _shuffle's round does key, sub = split(key) first
+  split2_lanes(kB, lane, unused, sub);
   int sel0, sel1;
-  shuffle_prefix(board, g, kB, N, lane, sel0, sel1);
+  shuffle_prefix(board, W, g, sub, N, g.thr, lane, sel0, sel1);
+#if defined(RBG_PROBE_STAGE) && RBG_PROBE_STAGE == 1  // developer probe: stop after the shuffle
+  w.r0 = w.c0 = w.r = w.c = sel0; w.P = 0;
+  return 0;
+#endif
   board_clear(board, g, lane);
   const uint32_t wire = 3u * (uint32_t)lane + 1u;
   w.r0 = w.c0 = w.r = w.c = 0;
@@ -296,6 +361,9 @@ __device__ __forceinline__ int prw_walk_impl(uint32_t *board, uint32_t *W, const
   wave_lds_fence();
 
   // pipeline prologue: W <- split(k_0, N), kcur <- k_1; then u <- u(0), W <- split(k_1, N), ...
+#if defined(RBG_PROBE_STAGE) && RBG_PROBE_STAGE == 2  // developer probe: stop before the prologue
+  return 0;
+#endif
   (void)prng_round<kSingle>(W, N, lane, kcur);
   float u = prng_round<kSingle>(W, N, lane, kcur);
 
@@ -341,16 +409,16 @@ __device__ __forceinline__ int prw_walk_impl(uint32_t *board, uint32_t *W, const
     if ((float)c1 >= rsel) dir = 0;
     const bool mover = c4 > 0;  // a blocked agent's -1 sentinel maps to NOOP / invalid UP (A.5)
     const int dP = dir == 0 ? -S : dir == 1 ? S : dir == 2 ? -1 : 1;
-    const int Q = P + dP;
+    // non-movers aim at word 0, a wall: max(wall, wire) leaves it unchanged (branch-free)
+    const int Q = mover ? P + dP : 0;
 
     // ---- _step_agents (:101-145): contested cell -> highest id wins, losers stay ----------
-    if (mover) atomicMax(&board[Q], wire);
+    atomicMax(&board[Q], wire);
     wave_lds_fence();
-    if (mover && board[Q] == wire) {
-      w.P = Q;
-      w.r += dir == 0 ? -1 : dir == 1 ? 1 : 0;
-      w.c += dir == 2 ? -1 : dir == 3 ? 1 : 0;
-    }
+    const bool won = board[Q] == wire;  // never true for the wall
+    w.P = won ? Q : P;
+    w.r += won ? (dir == 0 ? -1 : dir == 1 ? 1 : 0) : 0;
+    w.c += won ? (dir == 2 ? -1 : dir == 3 ? 1 : 0) : 0;
     u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
   }
 
@@ -568,6 +636,9 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;
   if (b >= a.B) return;  // wave-uniform; waves of a block never synchronise with each other
+#if defined(RBG_PROBE_STAGE) && RBG_PROBE_STAGE == 0
+  return;
+#endif
   uint32_t *board = g_lds + wib * wave_slab_words(a.g);
   uint32_t *W = board + wave_board_words(a.g);
   const Geo g = a.g;
@@ -575,7 +646,10 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   Key2 key;
   key.a = a.keys[2 * (size_t)b];
   key.b = a.keys[2 * (size_t)b + 1];
-  if (a.split_first) key = split2(key, 0);  // key, pos_key = split(key)  (generator :52)
+  if (a.split_first) {  // key, pos_key = split(key)  (generator :52)
+    Key2 unused;
+    split2_lanes(key, lane, key, unused);
+  }
 
   Walker w;
   const int iters = prw_walk(board, W, g, a.N, key, lane, w);
@@ -618,9 +692,11 @@ __global__ __launch_bounds__(kBlock) void uniform_generate_kernel(UniformArgs a)
   Key2 key;
   key.a = a.keys[2 * (size_t)b];
   key.b = a.keys[2 * (size_t)b + 1];
-  const Key2 kept = split2(key, 0), pos_key = split2(key, 1);
+  Key2 kept, pos_key, unused, sub;
+  split2_lanes(key, lane, kept, pos_key);
+  split2_lanes(pos_key, lane, unused, sub);
   int sel0, sel1;
-  shuffle_prefix(board, g, pos_key, 2 * a.N, lane, sel0, sel1);
+  shuffle_prefix(board, W, g, sub, 2 * a.N, g.thr, lane, sel0, sel1);
   // entry e of the prefix: e < N -> start of agent e, else target of agent e - N
   const int e_t = lane + a.N;  // prefix entry holding this agent's target
   const int t_lo = __shfl(sel0, e_t & 63), t_hi = __shfl(sel1, e_t & 63);
@@ -682,7 +758,8 @@ __device__ __forceinline__ void write_extras(const uint32_t *board, const Geo &g
 __device__ __forceinline__ void generate_state(uint32_t *board, uint32_t *W, const Geo &g, int N, int b,
                                                int lane, Key2 key_in, const StatePtrs &out,
                                                AgentRegs &ag) {
-  const Key2 key = split2(key_in, 0);
+  Key2 key, unused;
+  split2_lanes(key_in, lane, key, unused);
   Walker w;
   prw_walk(board, W, g, N, key, lane, w);
   board_to_training(board, g, lane);
@@ -795,7 +872,9 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     Key2 sk;
     sk.a = a.in.key[2 * (size_t)b];
     sk.b = a.in.key[2 * (size_t)b + 1];
-    generate_state(board, W, g, N, b, lane, split2(sk, 0), a.out, ag);
+    Key2 rk, unused;
+    split2_lanes(sk, lane, rk, unused);
+    generate_state(board, W, g, N, b, lane, rk, a.out, ag);
     write_observation(board, g, N, b, lane, ag, 0, a.ts);
     return;
   }
@@ -878,7 +957,17 @@ int check_hip(hipError_t e, const char *what) {
   return (int)e;
 }
 
-int make_geo(int m, int N, Geo *g) {
+// Candidate threshold of shuffle_prefix: about 3*count (24..44) of the n uniform 32-bit sort keys
+// are expected below it; 0 disables the fast path (count > 32, or the threshold would not fit).
+uint32_t prefix_threshold(int n, int count) {
+  if (count > 32) return 0u;
+  int expect = 3 * count;
+  expect = expect < 24 ? 24 : expect > 44 ? 44 : expect;
+  if (expect >= n) return 0u;
+  return (uint32_t)((((uint64_t)expect) << 32) / (uint64_t)n);
+}
+
+int make_geo(int m, int N, Geo *g, int prefix_count = -1) {
   if (m < 2 || m > kMaxM) return fail(RBG_E_SHAPE, "grid size m must be in [2, 40]");
   if (N < 1 || N > kMaxN) return fail(RBG_E_SHAPE, "num_agents N must be in [1, 64]");
   if (N > m * m) return fail(RBG_E_SHAPE, "num_agents N exceeds m*m cells");
@@ -887,6 +976,7 @@ int make_geo(int m, int N, Geo *g) {
   g->S = m + 4;
   g->words = (m + 4) * (m + 4);
   g->magic = ((1u << 20) + (uint32_t)m - 1u) / (uint32_t)m;
+  g->thr = prefix_threshold(m * m, prefix_count < 0 ? N : prefix_count);
   return 0;
 }
 
@@ -966,7 +1056,7 @@ int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *tra
                          int32_t *start, int32_t *target, uint32_t *key_out, void *stream) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_uniform_generate: B < 0");
   UniformArgs a;
-  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (int rc = make_geo(m, N, &a.g, 2 * N)) return rc;
   if (2 * N > m * m) return fail(RBG_E_SHAPE, "rbg_uniform_generate: 2N exceeds m*m cells");
   if (B == 0) return 0;
   if (!keys || !start || !target) return fail(RBG_E_NULL, "rbg_uniform_generate: NULL pointer");

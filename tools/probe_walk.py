@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--caps", type=str, default="")
+    ap.add_argument("--stages", type=str, default="",
+                    help="probe builds that stop early: 0 empty kernel, 1 after the shuffle, "
+                         "2 after board_clear (all with cap 0)")
     ap.add_argument("--batches", type=str, default="64,256,1024,2048,4096,8192,16384,65536")
     args = ap.parse_args()
     print(f"# {args.m}x{args.m}/{args.n}: kernel time (us, p50) vs batch")
@@ -75,6 +78,19 @@ def main():
         for B in (1024, 4096):
             us, mean_it, max_it = time_generate(B, args.m, args.n, lib=lib)
             print(f"cap={cap:4d} B={B:5d}  {us:9.1f} us  (iters mean {mean_it:.1f} max {max_it})")
+    probe_stages(args)
+
+
+def probe_stages(args):
+    for stage in [int(x) for x in args.stages.split(",") if x]:
+        so = os.path.join(ROOT, "gpurun_out", f"librbg_probe_stage{stage}.so")
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                              [f"-DRBG_PROBE_STAGE={stage}", "-DRBG_PROBE_MAX_ITERS=0", "-o", so,
+                               nat.SRC_PATH])
+        lib = C.CDLL(so)
+        for B in (1024, 4096):
+            us, _, _ = time_generate(B, args.m, args.n, lib=lib)
+            print(f"stage={stage} B={B:5d}  {us:9.1f} us")
 
 
 if __name__ == "__main__":
