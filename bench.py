@@ -49,6 +49,20 @@ def env_step_bytes(m: int, N: int) -> int:
     return read + write
 
 
+def measured_traffic(kernel: str, boards: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
+    written by tools/summarize_profile.py; counters cannot be read from inside this process).
+    Only valid for the launch shape it was measured on (B = 4096, 16x16/10)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")),
+                   key=os.path.getmtime)
+    if not files or boards != BATCH_PER_GPU:
+        return None
+    rec = json.load(open(files[-1]))["kernels"].get(kernel)
+    return rec["hbm_bytes_per_launch"] if rec else None
+
+
 def cpu_baseline(sample_batches: int):
     """Oracle (CPU port of the reference algorithm) on the same workload, all host threads."""
     import numpy as np  # noqa: F401
@@ -144,7 +158,9 @@ def main() -> None:
     achieved = B * bpb / (kernel_avg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "prw_generate_kernel", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "bytes_per_board": bpb, "boards_per_launch": B,
+                "traffic": measured_traffic("prw_generate_kernel", B),
+                "algorithmic_bytes_per_launch": B * bpb,
+                "bytes_per_board": bpb, "boards_per_launch": B,
                 "kernel_avg_ms": kernel_avg_ms,
                 "note": "latency-bound walk (serial dependent iterations per board): HBM fraction "
                         "reported for the record; see DESIGN.md"}
@@ -180,7 +196,9 @@ def main() -> None:
                     "policy": "rbg_random_actions (masked uniform)",
                     "roofline": {"bound": "hbm", "kernel": "connector_kernel", "achieved": ach,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": None, "bytes_per_env_step": sb,
+                                 "traffic": measured_traffic("connector_kernel", B),
+                                 "algorithmic_bytes_per_launch": B * sb,
+                                 "bytes_per_env_step": sb,
                                  "kernel_avg_ms": k_avg,
                                  "note": "duration of one env step = random_actions_kernel + "
                                          "connector_kernel (fused auto-reset walks included)"}}
