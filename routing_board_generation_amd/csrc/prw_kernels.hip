@@ -40,8 +40,14 @@ __device__ __forceinline__ uint32_t rotl(uint32_t x, int r) {
   x0 += x1;               \
   x1 = rotl(x1, r) ^ x0;
 
-__device__ __forceinline__ void threefry(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1,
-                                         uint32_t &y0, uint32_t &y1) {
+// The 20 rounds are split in two halves so that the walk loop can place each half in the shadow
+// of a different LDS round trip (see prw_walk_impl).
+struct TfState {
+  uint32_t x0, x1, k0, k1, k2;
+};
+
+__device__ __forceinline__ TfState threefry_first_half(uint32_t k0, uint32_t k1, uint32_t x0,
+                                                       uint32_t x1) {
   const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
   x0 += k0;
   x1 += k1;
@@ -51,6 +57,14 @@ __device__ __forceinline__ void threefry(uint32_t k0, uint32_t k1, uint32_t x0, 
   RBG_TF_ROUND(17) RBG_TF_ROUND(29) RBG_TF_ROUND(16) RBG_TF_ROUND(24)
   x0 += k2;
   x1 += k0 + 2u;
+  TfState t = {x0, x1, k0, k1, k2};
+  return t;
+}
+
+__device__ __forceinline__ void threefry_second_half(const TfState &t, uint32_t &y0,
+                                                     uint32_t &y1) {
+  uint32_t x0 = t.x0, x1 = t.x1;
+  const uint32_t k0 = t.k0, k1 = t.k1, k2 = t.k2;
   RBG_TF_ROUND(13) RBG_TF_ROUND(15) RBG_TF_ROUND(26) RBG_TF_ROUND(6)
   x0 += k0;
   x1 += k1 + 3u;
@@ -62,6 +76,21 @@ __device__ __forceinline__ void threefry(uint32_t k0, uint32_t k1, uint32_t x0, 
   x1 += k0 + 5u;
   y0 = x0;
   y1 = x1;
+}
+
+__device__ __forceinline__ void threefry(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1,
+                                         uint32_t &y0, uint32_t &y1) {
+  const TfState t = threefry_first_half(k0, k1, x0, x1);
+  threefry_second_half(t, y0, y1);
+}
+
+// Out-of-line copy for the once-per-board code (key derivation, sort keys, pipeline prologue):
+// that code is straight-line and executed once, so its cost is instruction FETCH, not issue;
+// sharing one Threefry body keeps it ~4 KB smaller.  The walk loop keeps its inlined halves.
+__device__ __noinline__ uint2 threefry_call(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1) {
+  uint32_t y0, y1;
+  threefry(k0, k1, x0, x1, y0, y1);
+  return make_uint2(y0, y1);
 }
 
 struct Key2 {
@@ -185,10 +214,9 @@ __device__ __forceinline__ void shuffle_prefix(uint32_t *scratch, uint32_t *aux,
   const uint32_t half = (n + 1u) >> 1;
   for (uint32_t j = lane; j < half; j += kWaveSize) {
     const bool has_hi = half + j < n;
-    uint32_t y0, y1;
-    threefry(sub.a, sub.b, j, has_hi ? half + j : 0u, y0, y1);
-    scratch[j] = y0;
-    if (has_hi) scratch[half + j] = y1;
+    const uint2 y = threefry_call(sub.a, sub.b, j, has_hi ? half + j : 0u);
+    scratch[j] = y.x;
+    if (has_hi) scratch[half + j] = y.y;
   }
   wave_lds_fence();
   sel0 = sel1 = -1;
@@ -254,8 +282,8 @@ __device__ __forceinline__ void shuffle_prefix(uint32_t *scratch, uint32_t *aux,
 // children (y0[0], y0[1]) and (y1[0], y1[1]) of blocks (0, 2) and (1, 3).
 __device__ __forceinline__ void split2_lanes(Key2 k, int lane, Key2 &child0, Key2 &child1) {
   const uint32_t x = (uint32_t)(lane & 1);
-  uint32_t y0, y1;
-  threefry(k.a, k.b, x, x + 2u, y0, y1);
+  const uint2 y = threefry_call(k.a, k.b, x, x + 2u);
+  const uint32_t y0 = y.x, y1 = y.y;
   child0.a = __builtin_amdgcn_readlane(y0, 0);
   child0.b = __builtin_amdgcn_readlane(y0, 1);
   child1.a = __builtin_amdgcn_readlane(y1, 0);
@@ -284,8 +312,7 @@ constexpr int kPrngScratchWords = 2 * kMaxN + 4;  // split(key, N) words of one 
 //   slot N + j, j < N   block j of split(k_{t+2}, N)     -> W (LDS), read by the next round
 //   slot 2N + x, x < 2  block x of split(k_{t+2})        -> k_{t+3} (wave-uniform, via readlane)
 // so the randomness of iteration t+1 is finished while iteration t waits on its LDS stencil.
-// kSingle: 2N + 2 <= 64, all slots fit one call (no loop; the Threefry block is straight-line
-// code the scheduler can interleave with the stencil).
+// kSingle: 2N + 2 <= 64, all slots fit one call (no loop).
 template <bool kSingle>
 __device__ __forceinline__ float prng_round(uint32_t *W, int N, int lane, Key2 &kcur) {
   const int twoN = 2 * N;
@@ -305,8 +332,8 @@ __device__ __forceinline__ float prng_round(uint32_t *W, int N, int lane, Key2 &
     // counters: uniform (0, pad 0) | split block j = s - N: (j, N + j) | split(k) block x: (x, x+2)
     const uint32_t c0 = r_uni ? 0u : r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
     const uint32_t c1 = r_uni ? 0u : r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
-    uint32_t y0, y1;
-    threefry(ka, kb, c0, c1, y0, y1);
+    const uint2 y = threefry_call(ka, kb, c0, c1);
+    const uint32_t y0 = y.x, y1 = y.y;
     if (r_uni) u = __fsub_rn(__uint_as_float((y0 >> 9) | 0x3F800000u), 1.0f);
     // out = y0-half ++ y1-half; other roles store to a dump slot (branch-free)
     W[r_split ? s - N : kPrngDumpSlot] = y0;
@@ -320,6 +347,51 @@ __device__ __forceinline__ float prng_round(uint32_t *W, int N, int lane, Key2 &
   kcur.a = nk0;
   kcur.b = nk1;
   return u;
+}
+
+// The single-call round cut in three pieces for software pipelining inside the walk loop:
+//   prng_issue   ds_read of this lane's uniform key (issued BEFORE the stencil reads so that
+//                waiting for it does not wait for them)
+//   prng_first   counters/keys + Threefry rounds 1-8   (runs under the stencil's LDS latency)
+//   prng_second  rounds 9-20, W stores, chain readlanes (runs under the move's ds_max + read-back)
+struct PrngLanes {  // per-lane constants of the single-call layout
+  bool r_uni, r_split;
+  int w_read, w_y0, w_y1;  // LDS word indices
+  uint32_t c0, c1;         // counters of the non-uniform roles
+  int chain_lane;
+};
+
+__device__ __forceinline__ PrngLanes prng_lanes(int N, int lane) {
+  PrngLanes p;
+  const int twoN = 2 * N, s = lane;
+  p.r_uni = s < N;
+  p.r_split = !p.r_uni && s < twoN;
+  p.w_read = p.r_uni ? 2 * s : 0;
+  p.w_y0 = p.r_split ? s - N : kPrngDumpSlot;
+  p.w_y1 = p.r_split ? s : kPrngDumpSlot + 1;
+  p.c0 = p.r_uni ? 0u : p.r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
+  p.c1 = p.r_uni ? 0u : p.r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
+  p.chain_lane = twoN;
+  return p;
+}
+
+__device__ __forceinline__ uint2 prng_issue(const uint32_t *W, const PrngLanes &p) {
+  return *reinterpret_cast<const uint2 *>(&W[p.w_read]);
+}
+
+__device__ __forceinline__ TfState prng_first(const PrngLanes &p, uint2 kk, Key2 kcur) {
+  return threefry_first_half(p.r_uni ? kk.x : kcur.a, p.r_uni ? kk.y : kcur.b, p.c0, p.c1);
+}
+
+__device__ __forceinline__ float prng_second(uint32_t *W, const PrngLanes &p, const TfState &t,
+                                             Key2 &kcur) {
+  uint32_t y0, y1;
+  threefry_second_half(t, y0, y1);
+  W[p.w_y0] = y0;
+  W[p.w_y1] = y1;
+  kcur.a = __builtin_amdgcn_readlane(y1, p.chain_lane);
+  kcur.b = __builtin_amdgcn_readlane(y1, p.chain_lane + 1);
+  return __fsub_rn(__uint_as_float((y0 >> 9) | 0x3F800000u), 1.0f);  // meaningful in r_uni lanes
 }
 
 // Runs generate_board(key) on `board` (LDS, padded).  On return the board holds the solved grid
@@ -368,6 +440,7 @@ __device__ __forceinline__ int prw_walk_impl(uint32_t *board, uint32_t *W, const
   float u = prng_round<kSingle>(W, N, lane, kcur);
 
   const int S = g.S;
+  const PrngLanes pl = prng_lanes(N, lane);
   int iters = 0;
   // Every iteration that runs moves at least the highest-id mover into an empty cell, so the
   // loop ends after at most n - N trips; the explicit bound keeps a faulty board from spinning.
@@ -377,6 +450,9 @@ __device__ __forceinline__ int prw_walk_impl(uint32_t *board, uint32_t *W, const
   const int max_iters = g.n;
 #endif
   for (; iters < max_iters; ++iters) {
+    // randomness of the NEXT iteration is independent of the board: its LDS read goes first ...
+    uint2 kk = make_uint2(0u, 0u);
+    if (kSingle) kk = prng_issue(W, pl);
     // ---- _available_cells for [up, down, left, right] (:293-374) -------------------------
     // candidate q is available iff it is empty and touches no cell of this wire other than the
     // head itself ("doubling back" counts the head once, so the other three must be foreign).
@@ -387,8 +463,19 @@ __device__ __forceinline__ int prw_walk_impl(uint32_t *board, uint32_t *W, const
     const uint32_t ul = board[P - S - 1], ur = board[P - S + 1];
     const uint32_t dl = board[P + S - 1], dr = board[P + S + 1];
 
-    // randomness of the NEXT iteration: independent of the board, overlaps the LDS latency above
-    const float u_next = prng_round<kSingle>(W, N, lane, kcur);
+    // ... and the first Threefry rounds run while the stencil reads are in flight
+    TfState tf = {0u, 0u, 0u, 0u, 0u};
+    float u_next = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+    if (kSingle) {
+      tf = prng_first(pl, kk, kcur);
+      // pin the half-finished state here: without it the optimiser sinks these rounds below
+      // the loop's exit test, i.e. out of the stencil's latency shadow
+      asm volatile("" : "+v"(tf.x0), "+v"(tf.x1));
+    } else {
+      u_next = prng_round<false>(W, N, lane, kcur);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     const bool own_ul = ul == wire, own_ur = ur == wire, own_dl = dl == wire, own_dr = dr == wire;
     const bool a_up = is_agent && vu == 0u && !(uu == wire || own_ul || own_ur);
@@ -415,10 +502,16 @@ __device__ __forceinline__ int prw_walk_impl(uint32_t *board, uint32_t *W, const
     // ---- _step_agents (:101-145): contested cell -> highest id wins, losers stay ----------
     atomicMax(&board[Q], wire);
     wave_lds_fence();
-    const bool won = board[Q] == wire;  // never true for the wall
+    const uint32_t after = board[Q];
+    __builtin_amdgcn_sched_barrier(0);
+    // the remaining Threefry rounds hide the ds_max + read-back round trip
+    if (kSingle) u_next = prng_second(W, pl, tf, kcur);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool won = after == wire;  // never true for the wall
     w.P = won ? Q : P;
     w.r += won ? (dir == 0 ? -1 : dir == 1 ? 1 : 0) : 0;
     w.c += won ? (dir == 2 ? -1 : dir == 3 ? 1 : 0) : 0;
+    wave_lds_fence();
     u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
   }
 

@@ -21,7 +21,7 @@ from routing_board_generation_amd import _native as nat  # noqa: E402
 from routing_board_generation_amd import ops  # noqa: E402
 
 
-def time_generate(B, m, N, reps=30, lib=None):
+def time_generate(B, m, N, reps=100, lib=None):
     keys = rbg.split(rbg.PRNGKey(0), B)
     out = ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_state=True,
                            want_iters=True)
@@ -42,15 +42,15 @@ def time_generate(B, m, N, reps=30, lib=None):
 
     for _ in range(5):
         launch()
-    evs = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        launch()
-        e1.record()
-        evs.append((e0, e1))
+    # back-to-back launches between ONE event pair: a pair per launch has a ~12 us floor here
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ts = [e0.elapsed_time(e1) / reps]
     it = out["iters"]
     return ts[len(ts) // 2] * 1e3, float(it.float().mean()), int(it.max())
 
