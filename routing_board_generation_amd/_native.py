@@ -68,9 +68,10 @@ def build_native(force: bool = False) -> str:
     """Compile csrc/prw_kernels.hip for gfx950 into lib/librbg_prw.so (hipcc cross-compiles
     without a GPU)."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    csrc = os.path.dirname(SRC_PATH)
+    sources = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [HEADER_PATH]
     stale = (not os.path.exists(LIB_PATH)
-             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(SRC_PATH),
-                                                 os.path.getmtime(HEADER_PATH)))
+             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in sources))
     if force or stale:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC_PATH]

@@ -1,0 +1,396 @@
+// rbg_walk.h -- the ParallelRandomWalk itself, one board per sub-wave (see rbg_device.h).
+//
+// Reference: JAXI/parallel_random_walk.py:60-145, 192-230, 262-374, 435-447
+// (JAXI = routing_board_generation/board_generation_methods/jax_implementation/board_generation).
+#pragma once
+#include "rbg_device.h"
+
+namespace rbg {
+
+// ---------------------------------------------------------------------------------------------
+// First `count` entries of jax's one-round _shuffle of arange(n):
+//   key, sub = split(key); sort_keys = random_bits(sub, n); stable sort -> ascending
+//   (sort_key, index).
+// No full sort: the first `count` entries are the `count` smallest (sort_key, index) pairs.
+//   fast path  a threshold `thr` (host-computed so that a few times `count` keys fall below it)
+//              filters the candidates, a ballot/popcount prefix compacts them into LDS, and
+//              every lane ranks its candidate against the others (LDS broadcast reads) -- exact
+//              whenever count <= #candidates <= LPB;
+//   slow path  otherwise (rare, or thr == 0): `count` sub-wave-wide 64-bit min-reductions.
+// Sub-lane l receives entry l in sel0 and entry LPB + l in sel1.
+// `scratch` needs n words (the board area is used), `aux` 2*LPB words.
+// ---------------------------------------------------------------------------------------------
+template <int LPB>
+__device__ __forceinline__ void shuffle_prefix(const SubWave<LPB> &sw, uint32_t *scratch,
+                                               uint32_t *aux, const Geo &g, Key2 sub, int count,
+                                               uint32_t thr, int &sel0, int &sel1) {
+  const uint32_t n = (uint32_t)g.n;
+  const uint32_t half = (n + 1u) >> 1;
+  const int l = sw.l;
+  for (uint32_t j = l; j < half; j += LPB) {
+    const bool has_hi = half + j < n;
+    const uint2 y = threefry_call(sub.a, sub.b, j, has_hi ? half + j : 0u);
+    scratch[j] = y.x;
+    if (has_hi) scratch[half + j] = y.y;
+  }
+  wave_lds_fence();
+  sel0 = sel1 = -1;
+
+  bool ok = false;
+  if (thr != 0u) {
+    // ---- compact the candidates (key < thr), in index order, as (key, index) pairs ----------
+    const uint64_t lt_mask = (1ull << l) - 1ull;
+    int total = 0;
+    for (uint32_t base = 0; base < n; base += LPB) {
+      const uint32_t j = base + l;
+      const uint32_t key = j < n ? scratch[j] : 0xFFFFFFFFu;
+      const bool flag = j < n && key < thr;
+      const uint64_t mask = sw.ballot(flag);
+      const int pos = total + __popcll(mask & lt_mask);
+      if (flag && pos < LPB) *reinterpret_cast<uint2 *>(&aux[2 * pos]) = make_uint2(key, j);
+      total += __popcll(mask);
+    }
+    wave_lds_fence();
+    ok = total >= count && total <= LPB;
+    // ---- rank every candidate among the candidates of its board -----------------------------
+    const int bound = min(sw.max_over_subs(total), LPB);
+    uint2 mine_kv = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (l < total && total <= LPB) mine_kv = *reinterpret_cast<const uint2 *>(&aux[2 * l]);
+    const uint64_t mine = ((uint64_t)mine_kv.x << 32) | mine_kv.y;
+    int rank = 0;
+    for (int c = 0; c < bound; ++c) {
+      const uint2 o = *reinterpret_cast<const uint2 *>(&aux[2 * c]);  // broadcast inside the board
+      rank += (int)(c < total && (((uint64_t)o.x << 32) | o.y) < mine);
+    }
+    wave_lds_fence();
+    if (ok && l < total) aux[rank] = mine_kv.y;  // ranks of distinct pairs form a permutation
+    wave_lds_fence();
+    if (ok && l < count) sel0 = (int)aux[l];
+    wave_lds_fence();
+  }
+  if (__ballot(!ok) == 0ull) return;
+
+  // ---- slow path (boards with ok == false): one 64-bit min-reduction per entry ---------------
+  uint64_t prev = 0;
+  bool have_prev = false;
+  for (int round = 0; round < count; ++round) {
+    uint64_t best = ~0ull;
+    for (uint32_t j = l; j < n; j += LPB) {
+      const uint64_t comp = ((uint64_t)scratch[j] << 32) | j;
+      if ((!have_prev || comp > prev) && comp < best) best = comp;
+    }
+    best = sw.min_u64(best);
+    prev = best;
+    have_prev = true;
+    const int cell = (int)(uint32_t)best;
+    if (!ok && round == l) sel0 = cell;
+    if (!ok && round == l + LPB) sel1 = cell;
+  }
+  wave_lds_fence();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lane-parallel PRNG pipeline.  A walk iteration consumes, per board,
+//   keys = split(k_t, N)  (N Threefry blocks),  u_i = uniform(keys[i])  (N blocks),
+//   k_{t+1} = split(k_t)[1]  (2 blocks)
+// none of which depends on the board.  The 2N + 2 blocks of one round are spread over the lanes
+// of the board's sub-wave as "virtual slots" and ONE Threefry evaluation serves three pipeline
+// stages at once:
+//   slot s < N          uniform(keys(t+1)[s])            -> u_s(t+1), lands in agent lane s
+//   slot N + j, j < N   block j of split(k_{t+2}, N)     -> W (LDS), read by the next round
+//   slot 2N + x, x < 2  block x of split(k_{t+2})        -> k_{t+3} (uniform per board)
+// so the randomness of iteration t+1 is finished while iteration t waits on its LDS stencil.
+// ---------------------------------------------------------------------------------------------
+template <int LPB>
+struct PrngLanes {  // per-lane constants of the single-evaluation layout (2N + 2 <= LPB)
+  bool r_uni, r_split;
+  int w_read, w_y0, w_y1;  // LDS word indices into W
+  uint32_t c0, c1;         // counters of this lane's role
+  int chain_lane;          // sub-lane of slot 2N
+};
+
+template <int LPB>
+__device__ __forceinline__ PrngLanes<LPB> prng_lanes(int N, int l) {
+  PrngLanes<LPB> p;
+  const int twoN = 2 * N, s = l, dump = 2 * LPB;
+  p.r_uni = s < N;
+  p.r_split = !p.r_uni && s < twoN;
+  p.w_read = p.r_uni ? 2 * s : 0;
+  // out = y0-half ++ y1-half; the other roles park their stores in a dump slot (branch-free)
+  p.w_y0 = p.r_split ? s - N : dump;
+  p.w_y1 = p.r_split ? s : dump + 1;
+  // counters: uniform (0, pad 0) | split block j = s - N: (j, N + j) | split(k) block x: (x, x+2)
+  p.c0 = p.r_uni ? 0u : p.r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
+  p.c1 = p.r_uni ? 0u : p.r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
+  p.chain_lane = twoN;
+  return p;
+}
+
+// The round cut in three pieces for software pipelining inside the walk loop:
+//   prng_issue   ds_read of this lane's uniform key (issued BEFORE the stencil reads so that
+//                waiting for it does not wait for them)
+//   prng_first   Threefry rounds 1-8   (runs under the stencil's LDS latency)
+//   prng_second  rounds 9-20, W stores, chain broadcast (runs under the move's ds_max + read-back)
+template <int LPB>
+__device__ __forceinline__ uint2 prng_issue(const uint32_t *W, const PrngLanes<LPB> &p) {
+  // unconditional (index-clamped) load: a pointer select would become a flat load via scratch
+  return *reinterpret_cast<const uint2 *>(&W[p.w_read]);
+}
+
+template <int LPB>
+__device__ __forceinline__ TfState prng_first(const PrngLanes<LPB> &p, uint2 kk, Key2 kcur) {
+  return threefry_first_half(p.r_uni ? kk.x : kcur.a, p.r_uni ? kk.y : kcur.b, p.c0, p.c1);
+}
+
+template <int LPB>
+__device__ __forceinline__ float prng_second(const SubWave<LPB> &sw, uint32_t *W,
+                                             const PrngLanes<LPB> &p, const TfState &t,
+                                             Key2 &kcur) {
+  uint32_t y0, y1;
+  threefry_second_half(t, y0, y1);
+  W[p.w_y0] = y0;
+  W[p.w_y1] = y1;
+  kcur.a = sw.bcast(y1, p.chain_lane);
+  kcur.b = sw.bcast(y1, p.chain_lane + 1);
+  return bits_to_uniform(y0);  // meaningful in the r_uni lanes
+}
+
+// One whole round, out of the loop (pipeline prologue) -- single evaluation.
+template <int LPB>
+__device__ __forceinline__ float prng_round_single(const SubWave<LPB> &sw, uint32_t *W,
+                                                   const PrngLanes<LPB> &p, Key2 &kcur) {
+  const uint2 kk = prng_issue<LPB>(W, p);
+  const uint2 y = threefry_call(p.r_uni ? kk.x : kcur.a, p.r_uni ? kk.y : kcur.b, p.c0, p.c1);
+  W[p.w_y0] = y.x;
+  W[p.w_y1] = y.y;
+  kcur.a = sw.bcast(y.y, p.chain_lane);
+  kcur.b = sw.bcast(y.y, p.chain_lane + 1);
+  wave_lds_fence();
+  return bits_to_uniform(y.x);
+}
+
+// One whole round when 2N + 2 > 64 (full-wave boards with N >= 32): two or three evaluations.
+__device__ __forceinline__ float prng_round_multi(uint32_t *W, int N, int lane, Key2 &kcur) {
+  const int twoN = 2 * N, dump = 2 * kWaveSize;
+  float u = 0.0f;
+  uint32_t nk0 = 0u, nk1 = 0u;
+#pragma unroll 1
+  for (int base = 0; base < twoN + 2; base += kWaveSize) {
+    const int s = base + lane;
+    const bool r_uni = s < N;
+    const bool r_split = !r_uni && s < twoN;
+    const uint2 kk = *reinterpret_cast<const uint2 *>(&W[r_uni ? 2 * s : 0]);
+    const uint32_t c0 = r_uni ? 0u : r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
+    const uint32_t c1 = r_uni ? 0u : r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
+    const uint2 y = threefry_call(r_uni ? kk.x : kcur.a, r_uni ? kk.y : kcur.b, c0, c1);
+    if (r_uni) u = bits_to_uniform(y.x);
+    W[r_split ? s - N : dump] = y.x;
+    W[r_split ? s : dump + 1] = y.y;
+    if (base == (twoN & ~(kWaveSize - 1))) {  // wave-uniform: the call that holds slots 2N, 2N+1
+      nk0 = __builtin_amdgcn_readlane(y.y, twoN & (kWaveSize - 1));
+      nk1 = __builtin_amdgcn_readlane(y.y, (twoN & (kWaveSize - 1)) + 1);
+    }
+  }
+  wave_lds_fence();
+  kcur.a = nk0;
+  kcur.b = nk1;
+  return u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The walk
+// ---------------------------------------------------------------------------------------------
+struct Walker {
+  int r0, c0;  // start (row, col)
+  int r, c;    // current head (row, col)
+  int P;       // padded index of the head
+  int iters;   // while_loop trip count of this lane's board
+};
+
+// Runs generate_board(key) for the board of this lane's sub-wave on `board` (LDS, padded) with
+// scratch `W`.  On return the board holds the solved grid with the head/target encodings of
+// :435-447 applied; sub-lanes i < N hold agent i's start / final position.
+//
+// During the walk every cell of wire i holds the single value 3i+1: the walk never needs to tell
+// a head from a path cell (availability only asks "empty?" and "own wire?"), and the value is
+// still monotone in the agent id, which is all the max-join needs.  Heads and targets are
+// written once at the end from the positions kept in registers.
+//
+// kSingle: 2N + 2 <= LPB, one Threefry evaluation per iteration, software-pipelined.
+template <int LPB, bool kSingle>
+__device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *board,
+                                              uint32_t *W, const Geo &g, int N, Key2 key,
+                                              Walker &w) {
+  const int l = sw.l;
+  Key2 kB, kcur, unused, sub;
+  split2_lanes(sw, key, kB, kcur);  // key, step_key = split(key)   (:73); kcur = k_0
+  const bool is_agent = l < N;
+
+  // _initialise_agents (:147-186): N distinct cells = first N of the shuffled arange(m*m);
+  // _shuffle's round does key, sub = split(key) first
+  split2_lanes(sw, kB, unused, sub);
+  int sel0, sel1;
+  shuffle_prefix(sw, board, W, g, sub, N, g.thr, sel0, sel1);
+  w.iters = 0;
+#if defined(RBG_PROBE_STAGE) && RBG_PROBE_STAGE == 1  // developer probe: stop after the shuffle
+  w.r0 = w.c0 = w.r = w.c = sel0;
+  w.P = 0;
+  return;
+#endif
+  board_clear<LPB>(board, g, l);
+  const uint32_t wire = 3u * (uint32_t)l + 1u;
+  w.r0 = w.c0 = w.r = w.c = 0;
+  w.P = pad_index(g, 0, 0);
+  if (is_agent) {
+    w.r0 = div_m(g, sel0);
+    w.c0 = sel0 - w.r0 * g.m;
+    w.r = w.r0;
+    w.c = w.c0;
+    w.P = pad_index(g, w.r, w.c);
+    board[w.P] = wire;
+  }
+  wave_lds_fence();
+#if defined(RBG_PROBE_STAGE) && RBG_PROBE_STAGE == 2  // developer probe: stop before the prologue
+  return;
+#endif
+
+  // pipeline prologue: W <- split(k_0, N), kcur <- k_1; then u <- u(0), W <- split(k_1, N), ...
+  const PrngLanes<LPB> pl = prng_lanes<LPB>(N, l);
+  float u;
+  if (kSingle) {
+    (void)prng_round_single(sw, W, pl, kcur);
+    u = prng_round_single(sw, W, pl, kcur);
+  } else {
+    (void)prng_round_multi(W, N, sw.lane, kcur);
+    u = prng_round_multi(W, N, sw.lane, kcur);
+  }
+
+  const int S = g.S;
+  // Every iteration that runs moves at least the highest-id mover of a live board into an empty
+  // cell, so a board is finished after at most n - N trips; the explicit bound keeps a faulty
+  // board from spinning.
+#ifdef RBG_PROBE_MAX_ITERS  // developer probe builds only (tools/probe_walk.py)
+  const int max_iters = g.n < RBG_PROBE_MAX_ITERS ? g.n : RBG_PROBE_MAX_ITERS;
+#else
+  const int max_iters = g.n;
+#endif
+  for (int t = 0; t < max_iters; ++t) {
+    // randomness of the NEXT iteration is independent of the board: its LDS read goes first ...
+    uint2 kk = make_uint2(0u, 0u);
+    if (kSingle) kk = prng_issue<LPB>(W, pl);
+    // ---- _available_cells for [up, down, left, right] (:293-374) -------------------------
+    // candidate q is available iff it is empty and touches no cell of this wire other than the
+    // head itself ("doubling back" counts the head once, so the other three must be foreign).
+    const int P = w.P;
+    const uint32_t vu = board[P - S], vd = board[P + S], vl = board[P - 1], vr = board[P + 1];
+    const uint32_t uu = board[P - 2 * S], dd = board[P + 2 * S];
+    const uint32_t ll = board[P - 2], rr = board[P + 2];
+    const uint32_t ul = board[P - S - 1], ur = board[P - S + 1];
+    const uint32_t dl = board[P + S - 1], dr = board[P + S + 1];
+
+    // ... and the first Threefry rounds run while the stencil reads are in flight
+    TfState tf = {0u, 0u, 0u, 0u, 0u};
+    float u_next = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+    if (kSingle) {
+      tf = prng_first<LPB>(pl, kk, kcur);
+      // pin the half-finished state here: without it the optimiser sinks these rounds below
+      // the loop's exit test, i.e. out of the stencil's latency shadow
+      asm volatile("" : "+v"(tf.x0), "+v"(tf.x1));
+    } else {
+      u_next = prng_round_multi(W, N, sw.lane, kcur);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const bool own_ul = ul == wire, own_ur = ur == wire, own_dl = dl == wire, own_dr = dr == wire;
+    const bool a_up = is_agent && vu == 0u && !(uu == wire || own_ul || own_ur);
+    const bool a_dn = is_agent && vd == 0u && !(dd == wire || own_dl || own_dr);
+    const bool a_lf = is_agent && vl == 0u && !(ll == wire || own_ul || own_dl);
+    const bool a_rt = is_agent && vr == 0u && !(rr == wire || own_ur || own_dr);
+    const int c1 = (int)a_up, c2 = c1 + (int)a_dn, c3 = c2 + (int)a_lf, c4 = c3 + (int)a_rt;
+
+    // ---- _continue_stepping (:192-203): a board stops when no agent has an available cell;
+    // a finished board stays finished (its grid no longer changes), so the other boards of the
+    // wave simply keep going until the last one is done.
+    const uint64_t live = __ballot(c4 > 0);
+    if (live == 0ull) break;
+    if (LPB == kWaveSize) {
+      w.iters += 1;
+    } else {
+      w.iters += (int)(((live >> (sw.h * LPB)) & ((1ull << (LPB & 63)) - 1ull)) != 0ull);
+    }
+
+    // ---- _select_action (:205-230): keys = split(key, N); choice(p = available) -----------
+    // choice: cum = cumsum(p); r = cum[-1] * (1 - uniform(key_i)); first index with cum >= r.
+    const float rsel = __fmul_rn((float)c4, __fsub_rn(1.0f, u));
+    int dir = 3;
+    if ((float)c3 >= rsel) dir = 2;
+    if ((float)c2 >= rsel) dir = 1;
+    if ((float)c1 >= rsel) dir = 0;
+    const bool mover = c4 > 0;  // a blocked agent's -1 sentinel maps to NOOP / invalid UP (A.5)
+    const int dP = dir == 0 ? -S : dir == 1 ? S : dir == 2 ? -1 : 1;
+    // non-movers aim at word 0, a wall: max(wall, wire) leaves it unchanged (branch-free)
+    const int Q = mover ? P + dP : 0;
+
+    // ---- _step_agents (:101-145): contested cell -> highest id wins, losers stay ----------
+    atomicMax(&board[Q], wire);
+    wave_lds_fence();
+    const uint32_t after = board[Q];
+    __builtin_amdgcn_sched_barrier(0);
+    // the remaining Threefry rounds hide the ds_max + read-back round trip
+    if (kSingle) u_next = prng_second<LPB>(sw, W, pl, tf, kcur);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool won = after == wire;  // never true for the wall
+    w.P = won ? Q : P;
+    w.r += won ? (dir == 0 ? -1 : dir == 1 ? 1 : 0) : 0;
+    w.c += won ? (dir == 2 ? -1 : dir == 3 ? 1 : 0) : 0;
+    wave_lds_fence();
+    u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
+  }
+
+  // update_solved_board_with_head_target_encodings (:435-447): heads first, then targets
+  if (is_agent) board[pad_index(g, w.r0, w.c0)] = wire + 1u;  // get_position(id)
+  wave_lds_fence();
+  if (is_agent) board[w.P] = wire + 2u;  // get_target(id); wins when the agent never moved
+  wave_lds_fence();
+}
+
+// Full-wave board (LPB = 64): pick the pipeline by N.
+__device__ __forceinline__ void prw_walk_full(const SubWave<64> &sw, uint32_t *board, uint32_t *W,
+                                              const Geo &g, int N, Key2 key, Walker &w) {
+  if (2 * N + 2 <= kWaveSize) {
+    prw_walk_impl<64, true>(sw, board, W, g, N, key, w);
+  } else {
+    prw_walk_impl<64, false>(sw, board, W, g, N, key, w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense int32 write-out of a padded board by its sub-wave.  kTrain: keep only heads and targets
+// (parallel_random_walk_generator.py:63-64): path cells (v % 3 == 1) become 0.
+// ---------------------------------------------------------------------------------------------
+template <int LPB, bool kTrain>
+__device__ __forceinline__ void store_grid(const uint32_t *board, const Geo &g, int l,
+                                           int32_t *__restrict__ out) {
+  if ((g.m & 3) == 0) {
+    // 4 consecutive cells never straddle a row; LDS rows are 16-B aligned (S % 4 == 0)
+    for (int idx = l * 4; idx < g.n; idx += LPB * 4) {
+      const int r = div_m(g, idx);
+      const uint4 v = *reinterpret_cast<const uint4 *>(&board[pad_index(g, r, idx - r * g.m)]);
+      int4 o;
+      o.x = (kTrain && v.x % 3u == 1u) ? 0 : (int)v.x;
+      o.y = (kTrain && v.y % 3u == 1u) ? 0 : (int)v.y;
+      o.z = (kTrain && v.z % 3u == 1u) ? 0 : (int)v.z;
+      o.w = (kTrain && v.w % 3u == 1u) ? 0 : (int)v.w;
+      *reinterpret_cast<int4 *>(&out[idx]) = o;
+    }
+  } else {
+    for (int idx = l; idx < g.n; idx += LPB) {
+      const int r = div_m(g, idx);
+      const uint32_t v = board[pad_index(g, r, idx - r * g.m)];
+      out[idx] = (kTrain && v % 3u == 1u) ? 0 : (int)v;
+    }
+  }
+}
+
+}  // namespace rbg
