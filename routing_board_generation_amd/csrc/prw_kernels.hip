@@ -546,6 +546,8 @@ int make_geo(int m, int N, Geo *g, int prefix_count = -1, int lpb = kWaveSize) {
   g->S = m + 4;
   g->words = (m + 4) * (m + 4);
   g->magic = ((1u << 20) + (uint32_t)m - 1u) / (uint32_t)m;
+  g->magic_s = ((1u << 20) + (uint32_t)g->S - 1u) / (uint32_t)g->S;
+  g->step_table = ((uint32_t)(-g->S) & 0xFFu) | ((uint32_t)g->S << 8) | (0xFFu << 16) | (1u << 24);
   g->thr = prefix_threshold(m * m, prefix_count < 0 ? N : prefix_count, lpb);
   return 0;
 }

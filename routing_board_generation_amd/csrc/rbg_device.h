@@ -201,6 +201,8 @@ struct Geo {
                 // serve as the right wall of the previous row)
   int words;    // (m + 4) * S: 2 wall rows above and below
   uint32_t magic;  // ceil(2^20 / m): idx / m == (idx * magic) >> 20 for idx * m < 2^20
+  uint32_t magic_s;  // ceil(2^20 / S): the same for the padded stride
+  uint32_t step_table;  // the four walk steps as signed bytes: [-S, +S, -1, +1] (up,down,left,right)
   uint32_t thr;    // shuffle_prefix candidate threshold for this launch's count (0 = slow path)
 };
 
@@ -209,6 +211,12 @@ __device__ __forceinline__ int pad_index(const Geo &g, int r, int c) {
 }
 __device__ __forceinline__ int div_m(const Geo &g, int idx) {
   return (int)(((uint32_t)idx * g.magic) >> 20);
+}
+// padded index -> (row, col)
+__device__ __forceinline__ void unpad_index(const Geo &g, int P, int &r, int &c) {
+  const int pr = (int)(((uint32_t)P * g.magic_s) >> 20);
+  r = pr - 2;
+  c = P - pr * g.S - 4;
 }
 __device__ __forceinline__ int board_words(const Geo &g) { return (g.words + 3) & ~3; }
 

@@ -315,9 +315,11 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     const uint64_t live = __ballot(c4 > 0);
     if (live == 0ull) break;
     if (LPB == kWaveSize) {
-      w.iters += 1;
+      w.iters = t + 1;
+    } else if (LPB == 32) {
+      w.iters = (sw.h ? (uint32_t)(live >> 32) : (uint32_t)live) != 0u ? t + 1 : w.iters;
     } else {
-      w.iters += (int)(((live >> (sw.h * LPB)) & ((1ull << (LPB & 63)) - 1ull)) != 0ull);
+      w.iters = ((live >> (sw.h * LPB)) & ((1ull << (LPB & 63)) - 1ull)) != 0ull ? t + 1 : w.iters;
     }
 
     // ---- _select_action (:205-230): keys = split(key, N); choice(p = available) -----------
@@ -328,7 +330,8 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     if ((float)c2 >= rsel) dir = 1;
     if ((float)c1 >= rsel) dir = 0;
     const bool mover = c4 > 0;  // a blocked agent's -1 sentinel maps to NOOP / invalid UP (A.5)
-    const int dP = dir == 0 ? -S : dir == 1 ? S : dir == 2 ? -1 : 1;
+    // step = signed byte `dir` of [-S, +S, -1, +1]: one shift + one v_bfe_i32
+    const int dP = __builtin_amdgcn_sbfe((int)g.step_table, (uint32_t)dir * 8u, 8u);
     // non-movers aim at word 0, a wall: max(wall, wire) leaves it unchanged (branch-free)
     const int Q = mover ? P + dP : 0;
 
@@ -342,12 +345,11 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     __builtin_amdgcn_sched_barrier(0);
     const bool won = after == wire;  // never true for the wall
     w.P = won ? Q : P;
-    w.r += won ? (dir == 0 ? -1 : dir == 1 ? 1 : 0) : 0;
-    w.c += won ? (dir == 2 ? -1 : dir == 3 ? 1 : 0) : 0;
     wave_lds_fence();
     u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
   }
 
+  unpad_index(g, w.P, w.r, w.c);  // the loop tracks the padded index only
   // update_solved_board_with_head_target_encodings (:435-447): heads first, then targets
   if (is_agent) board[pad_index(g, w.r0, w.c0)] = wire + 1u;  // get_position(id)
   wave_lds_fence();
