@@ -91,6 +91,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--env-steps", type=int, default=100,
                     help="env steps of the secondary Connector rollout measurement (0 = skip)")
+    ap.add_argument("--rollout-steps", type=int, default=50,
+                    help="env steps per launch of the fused random-policy rollout (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="batches of 4096 boards timed for cpu_baseline (0 = skip; default: "
                          "threads/4, i.e. ~20 core-seconds of CPU work)")
@@ -203,6 +205,36 @@ def main() -> None:
                                  "note": "duration of one env step = random_actions_kernel + "
                                          "connector_kernel (fused auto-reset walks included)"}}
 
+    # ---------------------------------------------------------------- secondary: fused rollout
+    rollout = None
+    if args.rollout_steps > 0:
+        st, _ = ops.connector_reset(keys, m, N)
+        stats = {k: torch.empty((B,), dtype=torch.int32, device=dev) for k in ops.ROLLOUT_STATS}
+        ops.connector_rollout(st, keys, 0, args.rollout_steps, state_out=st, stats=stats)
+        launches = 10
+        re0, re1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t2 = time.perf_counter()
+        re0.record()
+        for i in range(launches):
+            ops.connector_rollout(st, keys, (i + 1) * args.rollout_steps, args.rollout_steps,
+                                  state_out=st, stats=stats)
+        re1.record()
+        barrier()
+        r_elapsed = time.perf_counter() - t2
+        rm = sharding.all_reduce_metrics(
+            {"env_steps": float(B * args.rollout_steps * launches),
+             "episodes": float(stats["episodes"].sum().item()), "elapsed_s": r_elapsed}, device=dev)
+        rollout = {"metric": "env_steps_per_sec", "value": rm["env_steps"] / rm["elapsed_s"],
+                   "unit": "env-steps/s", "steps_per_launch": args.rollout_steps,
+                   "launches": launches, "auto_reset": True,
+                   "kernel": "connector_rollout_kernel",
+                   "kernel_avg_ms": re0.elapsed_time(re1) / launches,
+                   "episodes_per_launch": rm["episodes"],
+                   "note": "rbg_connector_rollout: random policy + step + fused auto-reset, env "
+                           "resident in LDS across steps; no per-step observation traffic, so not "
+                           "HBM-bound (state in/out once per launch)"}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         cpu = cpu_baseline(args.cpu_sample)
@@ -221,6 +253,7 @@ def main() -> None:
                        "mean_walk_iters": metrics["iters"] / (B * world),
                        "max_walk_iters": metrics["max_iters"]},
             "roofline": roofline, "cpu_baseline": cpu, "env_step": env_step,
+            "rollout": rollout,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -136,9 +136,36 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
 
 /* Masked-uniform random policy over the legal set (defined by this project; stands in for
  * [3P] jumanji.training.agents.random.RandomAgent in the rollout benchmark, BASELINE config 3):
- * agent i of env b picks legal action number random_bits(fold_in(keys[b], t), N)[i] mod #legal. */
+ * at global step t, agent i of env b picks legal action number
+ *   threefry2x32(keys[b], counter (t, i)).y0 mod #legal     (legal actions in ascending order). */
 int rbg_random_actions(const uint32_t *keys, int B, int N, uint32_t t, const uint8_t *action_mask,
                        int32_t *action, void *stream);
+
+/* Per-env counters of a rollout (all members nullable, each int32 [B], overwritten per call).
+ * Returns are integer counts so that they do not depend on a summation order:
+ *   episode return summed over agents and steps
+ *     = connected_reward * connections_made + timestep_reward * unconnected_agent_steps. */
+typedef struct rbg_rollout_stats {
+  int32_t *episodes;                /* timesteps with step_type LAST */
+  int32_t *connections_made;        /* agent connection events */
+  int32_t *unconnected_agent_steps; /* (agent, step) pairs that began the step unconnected */
+  int32_t *final_connections;       /* sum over ended episodes of num_connections at LAST */
+  int32_t *final_path_length;       /* sum over ended episodes of total_path_length at LAST */
+} rbg_rollout_stats;
+
+/* n_steps of VmapAutoResetWrapper(Connector).step under the rbg_random_actions policy (global
+ * steps t0 .. t0 + n_steps - 1) in ONE launch: the rollout loop of
+ * routing_board_generation/benchmarking/benchmarks/benchmark_on_random_agent.py:59-102 /
+ * agent_training/training_script.py:70-79 with [3P] jumanji's RandomAgent.
+ * Equivalent to n_steps x { rbg_random_actions; rbg_connector_step } with the same params, but
+ * the env lives in LDS between steps: no per-step state or observation traffic.
+ * state_out may alias state_in.  last_timestep (nullable, members nullable) receives the
+ * timestep of the final step exactly as rbg_connector_step would have returned it. */
+int rbg_connector_rollout(int B, int m, int N, const rbg_state *state_in,
+                          const rbg_state *state_out, const uint32_t *policy_keys, uint32_t t0,
+                          int n_steps, const rbg_env_params *params,
+                          const rbg_rollout_stats *stats, const rbg_timestep *last_timestep,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -300,3 +300,34 @@ def random_actions_batch(keys, t, action_mask):
 
 def copy_state(st):
     return {k: v.copy() for k, v in st.items()}
+
+
+ROLLOUT_STATS = ("episodes", "connections_made", "unconnected_agent_steps", "final_connections",
+                 "final_path_length")
+
+
+def connector_rollout_batch(st, policy_keys, t0, n_steps, time_limit=50, timestep_reward=-0.03,
+                            connected_reward=0.1, auto_reset=True, threads=1):
+    """n_steps x { random_actions_batch; connector_step_batch } with the per-env counters of
+    rbg_rollout_stats.  Steps `st` IN PLACE; returns (stats dict, timestep of the last step)."""
+    B = st["grid"].shape[0]
+    stats = {k: np.zeros((B,), np.int32) for k in ROLLOUT_STATS}
+    mask = connector_observe_batch(st, threads=threads)["action_mask"]
+    ts = None
+    for s in range(n_steps):
+        act = random_actions_batch(policy_keys, t0 + s, mask)
+        was = (st["position"] == st["target"]).all(-1)
+        probe = copy_state(st)  # the stepped state BEFORE any auto-reset, for the counters
+        connector_step_batch(probe, act, time_limit, timestep_reward, connected_reward,
+                             auto_reset=False, threads=threads)
+        now = (probe["position"] == probe["target"]).all(-1)
+        ts = connector_step_batch(st, act, time_limit, timestep_reward, connected_reward,
+                                  auto_reset=auto_reset, threads=threads)
+        last = ts["step_type"] == 2
+        stats["connections_made"] += (~was & now).sum(-1).astype(np.int32)
+        stats["unconnected_agent_steps"] += (~was).sum(-1).astype(np.int32)
+        stats["episodes"] += last.astype(np.int32)
+        stats["final_connections"] += np.where(last, ts["num_connections"], 0).astype(np.int32)
+        stats["final_path_length"] += np.where(last, ts["total_path_length"], 0).astype(np.int32)
+        mask = ts["action_mask"]
+    return stats, ts

@@ -735,26 +735,26 @@ int oracle_connector_step_batch(int B, int m, int N, int32_t *grid, int32_t *ste
 }
 
 /* Masked-uniform random policy "defined by this project" (the reference's RandomAgent lives in
- * jumanji.training and draws a Gumbel categorical; nothing pins it).  Agent i of env b at step t
- * uses bits = random_bits(fold(key_b, t))[i] and picks the (bits mod count)-th legal action. */
+ * jumanji.training and draws a Gumbel categorical; nothing pins it).  At global step t, agent i of
+ * env b picks legal action number threefry2x32(key_b, counter (t, i)).y0 mod #legal, legal actions
+ * in ascending order. */
 void oracle_random_actions_batch(const uint32_t *keys /*[B][2]*/, int B, int N, uint32_t t,
                                  const uint8_t *action_mask /*[B][N][5]*/,
                                  int32_t *action /*[B][N]*/) {
   for (int b = 0; b < B; ++b) {
-    uint32_t bits[ORACLE_MAX_AGENTS];
-    uint32_t kt[2], o0, o1;
-    oracle_threefry2x32(keys[2 * b], keys[2 * b + 1], 0u, t, &o0, &o1); /* fold_in(key, t) */
-    kt[0] = o0;
-    kt[1] = o1;
-    oracle_random_bits(kt, N, bits);
     for (int i = 0; i < N; ++i) {
       const uint8_t *mk = action_mask + ((size_t)b * N + i) * 5;
+      uint32_t y0, y1;
+      oracle_threefry2x32(keys[2 * b], keys[2 * b + 1], t, (uint32_t)i, &y0, &y1);
       int cnt = 0;
       for (int a = 0; a < 5; ++a) cnt += mk[a] != 0;
-      int pick = (int)(bits[i] % (uint32_t)cnt), a = 0;
+      int pick = (int)(y0 % (uint32_t)(cnt > 0 ? cnt : 1)), a = 0, chosen = 0;
       for (a = 0; a < 5; ++a)
-        if (mk[a] && pick-- == 0) break;
-      action[(size_t)b * N + i] = a;
+        if (mk[a] && pick-- == 0) {
+          chosen = a;
+          break;
+        }
+      action[(size_t)b * N + i] = chosen;
     }
   }
 }

@@ -35,6 +35,12 @@ class Timestep(C.Structure):
                 ("ratio_connections", C.c_void_p), ("total_path_length", C.c_void_p)]
 
 
+class RolloutStats(C.Structure):
+    _fields_ = [("episodes", C.c_void_p), ("connections_made", C.c_void_p),
+                ("unconnected_agent_steps", C.c_void_p), ("final_connections", C.c_void_p),
+                ("final_path_length", C.c_void_p)]
+
+
 class EnvParams(C.Structure):
     _fields_ = [("time_limit", C.c_int32), ("timestep_reward", C.c_float),
                 ("connected_reward", C.c_float), ("auto_reset", C.c_int32)]
@@ -59,6 +65,10 @@ SIGNATURES = {
     "rbg_connector_step": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
                                      C.POINTER(State), C.c_void_p, C.POINTER(EnvParams),
                                      C.POINTER(Timestep), C.c_void_p]),
+    "rbg_connector_rollout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
+                                        C.POINTER(State), C.c_void_p, C.c_uint32, C.c_int,
+                                        C.POINTER(EnvParams), C.POINTER(RolloutStats),
+                                        C.POINTER(Timestep), C.c_void_p]),
     "rbg_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
 }

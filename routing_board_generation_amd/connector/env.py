@@ -107,6 +107,23 @@ class Connector:
             so, ts = self._generic_auto_reset(so, ts)
         return _make_state(so, batched), _make_timestep(ts, batched)
 
+    # ---------------------------------------------------------------------------------- rollout
+    def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,
+                       want_timestep: bool = False):
+        """n_steps of `step` under the masked-uniform random policy (ops.random_actions) in ONE
+        kernel launch: the rollout loop of benchmark_on_random_agent.py:59-102 with jumanji's
+        RandomAgent.  Batched states only.  Returns (state, stats, timestep-of-the-last-step or
+        None); stats are per-env int32 counters (include/rbg_prw.h::rbg_rollout_stats)."""
+        if state.grid.dim() != 3:
+            raise ValueError("random_rollout expects a batched state")
+        if self._auto_reset and not isinstance(self._generator, ParallelRandomWalkGenerator):
+            raise NotImplementedError("fused rollouts need the ParallelRandomWalkGenerator")
+        so, stats, ts = ops.connector_rollout(
+            _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
+            self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
+            auto_reset=self._auto_reset, want_timestep=want_timestep)
+        return _make_state(so, True), stats, (_make_timestep(ts, True) if ts is not None else None)
+
     def _generic_auto_reset(self, so, ts):
         """VmapAutoResetWrapper for generators without a fused kernel: regenerate every env from
         split(state.key)[0] and select where the timestep is LAST (what vmap(lax.cond) does)."""

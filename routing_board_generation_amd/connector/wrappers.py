@@ -52,3 +52,8 @@ class VmapAutoResetWrapper(_Wrapper):
 
     def step(self, state: State, action: torch.Tensor) -> Tuple[State, TimeStep]:
         return self._env.step(state, action)
+
+    def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,
+                       want_timestep: bool = False):
+        """n_steps of auto-resetting random-policy stepping in one launch (Connector.random_rollout)."""
+        return self._env.unwrapped.random_rollout(state, policy_keys, t0, n_steps, want_timestep)

@@ -21,152 +21,11 @@
 #include "../../include/rbg_prw.h"
 #include "rbg_device.h"
 #include "rbg_walk.h"
+#include "rbg_env.h"
 
 namespace {
 
 using namespace rbg;
-
-// HBM int32 grid -> padded LDS board
-__device__ __forceinline__ void load_grid(uint32_t *board, const Geo &g, int lane,
-                                          const int32_t *__restrict__ in) {
-  for (int w = lane; w < g.words; w += kWaveSize) board[w] = kWall;
-  wave_lds_fence();
-  if ((g.m & 3) == 0) {
-    for (int idx = lane * 4; idx < g.n; idx += kWaveSize * 4) {
-      const int r = div_m(g, idx);
-      const int4 v = *reinterpret_cast<const int4 *>(&in[idx]);
-      *reinterpret_cast<uint4 *>(&board[pad_index(g, r, idx - r * g.m)]) =
-          make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
-    }
-  } else {
-    for (int idx = lane; idx < g.n; idx += kWaveSize) {
-      const int r = div_m(g, idx);
-      board[pad_index(g, r, idx - r * g.m)] = (uint32_t)in[idx];
-    }
-  }
-  wave_lds_fence();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Connector observation pieces ([3P] jumanji connector/env.py)
-// ---------------------------------------------------------------------------------------------
-struct AgentRegs {
-  int r0, c0;  // start
-  int tr, tc;  // target
-  int r, c;    // position
-};
-
-// _get_action_mask: bits 0..4 = NOOP, UP, RIGHT, DOWN, LEFT
-__device__ __forceinline__ uint32_t action_mask_bits(const uint32_t *board, const Geo &g,
-                                                     const AgentRegs &a, int lane) {
-  const bool connected = a.r == a.tr && a.c == a.tc;
-  const int P = pad_index(g, a.r, a.c);
-  const uint32_t tgt = 3u * (uint32_t)lane + 3u;
-  const uint32_t vu = board[P - g.S], vr = board[P + 1], vd = board[P + g.S], vl = board[P - 1];
-  uint32_t bits = 1u;
-  if (!connected) {
-    bits |= (uint32_t)(vu == 0u || vu == tgt) << 1;
-    bits |= (uint32_t)(vr == 0u || vr == tgt) << 2;
-    bits |= (uint32_t)(vd == 0u || vd == tgt) << 3;
-    bits |= (uint32_t)(vl == 0u || vl == tgt) << 4;
-  }
-  return bits;
-}
-
-// _obs_from_grid: agent i sees v > 0 as ((v - 1 - 3 i) mod 3N) + 1 (own cells become 1, 2, 3)
-__device__ __forceinline__ int obs_value(uint32_t v, int i3, int n3) {
-  int t = (int)v - 1 - i3;
-  t += t < 0 ? n3 : 0;
-  return v == 0u ? 0 : t + 1;
-}
-
-__device__ __forceinline__ void store_obs(const uint32_t *board, const Geo &g, int N, int lane,
-                                          int32_t *__restrict__ obs) {
-  const int n3 = 3 * N;
-  if ((g.m & 3) == 0) {
-    for (int idx = lane * 4; idx < g.n; idx += kWaveSize * 4) {
-      const int r = div_m(g, idx);
-      const uint4 v = *reinterpret_cast<const uint4 *>(&board[pad_index(g, r, idx - r * g.m)]);
-      for (int i = 0; i < N; ++i) {
-        int4 o;
-        o.x = obs_value(v.x, 3 * i, n3);
-        o.y = obs_value(v.y, 3 * i, n3);
-        o.z = obs_value(v.z, 3 * i, n3);
-        o.w = obs_value(v.w, 3 * i, n3);
-        *reinterpret_cast<int4 *>(&obs[(size_t)i * g.n + idx]) = o;
-      }
-    }
-  } else {
-    for (int idx = lane; idx < g.n; idx += kWaveSize) {
-      const int r = div_m(g, idx);
-      const uint32_t v = board[pad_index(g, r, idx - r * g.m)];
-      for (int i = 0; i < N; ++i) obs[(size_t)i * g.n + idx] = obs_value(v, 3 * i, n3);
-    }
-  }
-}
-
-// number of PATH cells (v % 3 == 1), the `total_path_length` extra
-__device__ __forceinline__ int count_path_cells(const uint32_t *board, const Geo &g, int lane) {
-  int cnt = 0;
-  for (int idx = lane; idx < g.n; idx += kWaveSize) {
-    const int r = div_m(g, idx);
-    cnt += (int)(board[pad_index(g, r, idx - r * g.m)] % 3u == 1u);
-  }
-  return SubWave<64>(lane).sum_i32(cnt);
-}
-
-struct TimestepPtrs {
-  int8_t *step_type;
-  float *reward;
-  float *discount;
-  int32_t *obs_grid;
-  uint8_t *action_mask;
-  int32_t *obs_step_count;
-  int32_t *num_connections;
-  float *ratio_connections;
-  int32_t *total_path_length;
-};
-struct StatePtrs {
-  int32_t *grid;
-  int32_t *step_count;
-  int32_t *start;
-  int32_t *target;
-  int32_t *position;
-  uint32_t *key;
-};
-
-__device__ __forceinline__ void store_mask(const TimestepPtrs &ts, int b, int N, int lane,
-                                           uint32_t bits) {
-  if (ts.action_mask && lane < N) {
-    uint8_t *p = ts.action_mask + ((size_t)b * N + lane) * 5;
-#pragma unroll
-    for (int a = 0; a < 5; ++a) p[a] = (uint8_t)((bits >> a) & 1u);
-  }
-}
-
-__device__ __forceinline__ void store_agents(const StatePtrs &st, int b, int N, int lane,
-                                             const AgentRegs &a, bool with_start_target) {
-  if (lane < N) {
-    const size_t o = ((size_t)b * N + lane) * 2;
-    if (with_start_target) {
-      *reinterpret_cast<int2 *>(&st.start[o]) = make_int2(a.r0, a.c0);
-      *reinterpret_cast<int2 *>(&st.target[o]) = make_int2(a.tr, a.tc);
-    }
-    *reinterpret_cast<int2 *>(&st.position[o]) = make_int2(a.r, a.c);
-  }
-}
-
-// Builds a fresh State from a finished walk (parallel_random_walk_generator.py:58-77) and turns
-// the LDS board into the training grid (heads + targets only).
-__device__ __forceinline__ void board_to_training(uint32_t *board, const Geo &g, int lane) {
-  for (int idx = lane; idx < g.n; idx += kWaveSize) {
-    const int r = div_m(g, idx);
-    const int p = pad_index(g, r, idx - r * g.m);
-    const uint32_t v = board[p];
-    if (v % 3u == 1u) board[p] = 0u;
-  }
-  wave_lds_fence();
-}
 
 // ---------------------------------------------------------------------------------------------
 // Kernels
@@ -298,53 +157,85 @@ struct EnvArgs {
   int mode;  // 0 reset (generate), 1 observe existing state, 2 step
 };
 
-// Observation + extras of the state held in (board, ag); `terminal` keeps reward/discount/
-// step_type/extras of the step that just ended when the env was auto-reset.
-__device__ __forceinline__ void write_observation(const uint32_t *board, const Geo &g, int N,
-                                                  int b, int lane, const AgentRegs &ag,
-                                                  int step_count, const TimestepPtrs &ts) {
-  const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
-  store_mask(ts, b, N, lane, bits);
-  if (ts.obs_grid) store_obs(board, g, N, lane, ts.obs_grid + (size_t)b * N * g.n);
-  if (ts.obs_step_count && lane == 0) ts.obs_step_count[b] = step_count;
-}
-
-__device__ __forceinline__ void write_extras(const uint32_t *board, const Geo &g, int N, int b,
-                                             int lane, const AgentRegs &ag,
-                                             const TimestepPtrs &ts) {
-  const bool connected = lane < N && ag.r == ag.tr && ag.c == ag.tc;
-  const int conn = __popcll(__ballot(connected));
-  const int plen = ts.total_path_length ? count_path_cells(board, g, lane) : 0;
-  if (lane == 0) {
-    if (ts.num_connections) ts.num_connections[b] = conn;
-    if (ts.ratio_connections) ts.ratio_connections[b] = __fdiv_rn((float)conn, (float)N);
-    if (ts.total_path_length) ts.total_path_length[b] = plen;
-  }
-}
-
-// Generator -> State: runs the walk for `key_in` (the generator's argument), leaves the training
-// grid in LDS, fills agent registers, writes the State to HBM.
-__device__ __forceinline__ void generate_state(uint32_t *board, uint32_t *W, const Geo &g, int N, int b,
-                                               int lane, Key2 key_in, const StatePtrs &out,
-                                               AgentRegs &ag) {
-  const SubWave<64> sw(lane);
-  Key2 key, unused;
-  split2_lanes(sw, key_in, key, unused);
-  Walker w;
-  prw_walk_full(sw, board, W, g, N, key, w);
-  board_to_training(board, g, lane);
-  ag.r0 = w.r0; ag.c0 = w.c0;
-  ag.tr = w.r;  ag.tc = w.c;
-  ag.r = w.r0;  ag.c = w.c0;
-  store_grid<64, false>(board, g, lane, out.grid + (size_t)b * g.n);
-  store_agents(out, b, N, lane, ag, true);
-  if (lane == 0) {
-    out.step_count[b] = 0;
-    *reinterpret_cast<uint2 *>(&out.key[2 * (size_t)b]) = make_uint2(key.a, key.b);
-  }
-}
-
 __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
+  const int lane = threadIdx.x & (kWaveSize - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * kWavesPerBlock + wib;
+  if (b >= a.B) return;
+  uint32_t *board = g_lds + wib * slab_words<64>(a.g);
+  uint32_t *W = board + board_words(a.g);
+  const Geo g = a.g;
+  const int N = a.N;
+  AgentRegs ag = {0, 0, 0, 0, 0, 0};
+
+  if (a.mode == 0) {  // ---- Connector.reset ---------------------------------------------------
+    Key2 kin;
+    kin.a = a.keys[2 * (size_t)b];
+    kin.b = a.keys[2 * (size_t)b + 1];
+    const Key2 key = regenerate(board, W, g, N, lane, kin, ag);
+    store_state(board, g, N, b, lane, ag, 0, key, a.out);
+    write_observation(board, g, N, b, lane, ag, 0, a.ts);
+    write_extras(board, g, N, b, lane, ag, a.ts);
+    write_restart(N, b, lane, a.ts);
+    return;
+  }
+
+  int step_count;
+  Key2 key;
+  load_state(board, g, N, b, lane, a.in, ag, step_count, key);
+
+  if (a.mode == 1) {  // ---- observe an existing state (restart timestep) ----------------------
+    write_observation(board, g, N, b, lane, ag, step_count, a.ts);
+    write_extras(board, g, N, b, lane, ag, a.ts);
+    write_restart(N, b, lane, a.ts);
+    return;
+  }
+
+  // ---- Connector.step --------------------------------------------------------------------------
+  const int act = lane < N ? a.action[(size_t)b * N + lane] : 0;
+  const StepResult res = env_step_core(board, g, N, lane, ag, step_count, act, a.p.time_limit);
+  write_step_outcome(res, a.p, N, b, lane, a.ts);
+  write_extras(board, g, N, b, lane, ag, a.ts);
+
+  if (res.last && a.p.auto_reset) {
+    // VmapAutoResetWrapper._auto_reset: key, _ = split(state.key); state, ts = reset(key);
+    // only the observation of the terminal timestep is replaced.
+    Key2 rk, unused;
+    split2_lanes(SubWave<64>(lane), key, rk, unused);
+    key = regenerate(board, W, g, N, lane, rk, ag);
+    step_count = 0;
+  }
+  store_state(board, g, N, b, lane, ag, step_count, key, a.out);
+  write_observation(board, g, N, b, lane, ag, step_count, a.ts);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Random-policy rollout: n_steps of VmapAutoResetWrapper(Connector).step under the masked-uniform
+// policy in ONE launch.  The env stays in LDS/registers between steps, so HBM sees the state once
+// in and once out (+ a few counters) instead of ~13 KB per env-step, and envs that regenerate do
+// so while the others keep stepping (no per-step launch boundary to wait at).
+// ---------------------------------------------------------------------------------------------
+struct RolloutStatsPtrs {
+  int32_t *episodes;
+  int32_t *connections_made;
+  int32_t *unconnected_agent_steps;
+  int32_t *final_connections;
+  int32_t *final_path_length;
+};
+
+struct RolloutArgs {
+  int B, N;
+  Geo g;
+  StatePtrs in, out;
+  const uint32_t *policy_keys;
+  uint32_t t0;
+  int n_steps;
+  rbg_env_params p;
+  RolloutStatsPtrs stats;
+  TimestepPtrs ts;  // timestep of the LAST step of the rollout (all members nullable)
+};
+
+__global__ __launch_bounds__(kBlock) void connector_rollout_kernel(RolloutArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;
@@ -355,113 +246,47 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   const int N = a.N;
   const bool is_agent = lane < N;
   AgentRegs ag = {0, 0, 0, 0, 0, 0};
+  int step_count;
+  Key2 key, pk;
+  load_state(board, g, N, b, lane, a.in, ag, step_count, key);
+  pk.a = a.policy_keys[2 * (size_t)b];
+  pk.b = a.policy_keys[2 * (size_t)b + 1];
 
-  if (a.mode == 0) {  // ---- Connector.reset ---------------------------------------------------
-    Key2 kin;
-    kin.a = a.keys[2 * (size_t)b];
-    kin.b = a.keys[2 * (size_t)b + 1];
-    generate_state(board, W, g, N, b, lane, kin, a.out, ag);
-    write_observation(board, g, N, b, lane, ag, 0, a.ts);
-    write_extras(board, g, N, b, lane, ag, a.ts);
-    if (is_agent) {
-      if (a.ts.reward) a.ts.reward[(size_t)b * N + lane] = 0.0f;
-      if (a.ts.discount) a.ts.discount[(size_t)b * N + lane] = 1.0f;
+  int episodes = 0, conn_made = 0, pen_steps = 0, fin_conn = 0, fin_plen = 0;
+  uint32_t bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
+  for (int s = 0; s < a.n_steps; ++s) {
+    const int act = random_policy_action(pk, a.t0 + (uint32_t)s, (uint32_t)lane, bits);
+    const StepResult res = env_step_core(board, g, N, lane, ag, step_count, act, a.p.time_limit);
+    bits = res.bits;
+    conn_made += __popcll(__ballot(!res.was_connected && res.connected));
+    pen_steps += __popcll(__ballot(is_agent && !res.was_connected));
+    const bool final_step = s == a.n_steps - 1;
+    if (final_step) {
+      write_step_outcome(res, a.p, N, b, lane, a.ts);
+      write_extras(board, g, N, b, lane, ag, a.ts);
     }
-    if (lane == 0 && a.ts.step_type) a.ts.step_type[b] = 0;
-    return;
-  }
-
-  // ---- load the state ------------------------------------------------------------------------
-  load_grid(board, g, lane, a.in.grid + (size_t)b * g.n);
-  if (is_agent) {
-    const size_t o = ((size_t)b * N + lane) * 2;
-    const int2 s = *reinterpret_cast<const int2 *>(&a.in.start[o]);
-    const int2 t = *reinterpret_cast<const int2 *>(&a.in.target[o]);
-    const int2 p = *reinterpret_cast<const int2 *>(&a.in.position[o]);
-    ag.r0 = s.x; ag.c0 = s.y; ag.tr = t.x; ag.tc = t.y; ag.r = p.x; ag.c = p.y;
-  }
-  int step_count = a.in.step_count[b];
-
-  if (a.mode == 1) {  // ---- observe an existing state (restart timestep) ----------------------
-    write_observation(board, g, N, b, lane, ag, step_count, a.ts);
-    write_extras(board, g, N, b, lane, ag, a.ts);
-    if (is_agent) {
-      if (a.ts.reward) a.ts.reward[(size_t)b * N + lane] = 0.0f;
-      if (a.ts.discount) a.ts.discount[(size_t)b * N + lane] = 1.0f;
+    if (res.last) {
+      episodes += 1;
+      fin_conn += __popcll(__ballot(res.connected));
+      if (a.stats.final_path_length) fin_plen += count_path_cells(board, g, lane);
+      if (a.p.auto_reset) {
+        Key2 rk, unused;
+        split2_lanes(SubWave<64>(lane), key, rk, unused);
+        key = regenerate(board, W, g, N, lane, rk, ag);
+        step_count = 0;
+        bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
+      }
     }
-    if (lane == 0 && a.ts.step_type) a.ts.step_type[b] = 0;
-    return;
   }
-
-  // ---- Connector.step --------------------------------------------------------------------------
-  // _step_agent: move iff the action is not NOOP, the destination is in bounds and empty or the
-  // agent's own target, and the agent is not connected yet.
-  const uint32_t head = 3u * (uint32_t)lane + 2u;
-  const bool was_connected = is_agent && ag.r == ag.tr && ag.c == ag.tc;
-  int act = is_agent ? a.action[(size_t)b * N + lane] : 0;
-  act = act < 0 ? 0 : act > 4 ? 4 : act;  // lax.switch clamps its index (move_position)
-  const int dr = act == 1 ? -1 : act == 3 ? 1 : 0;
-  const int dc = act == 2 ? 1 : act == 4 ? -1 : 0;
-  const int P = pad_index(g, ag.r, ag.c);
-  const int Q = P + dr * g.S + dc;
-  const uint32_t vq = board[Q];
-  const bool to_empty = vq == 0u;
-  const bool to_target = vq == head + 1u;
-  const bool mover = is_agent && act != 0 && !was_connected && (to_empty || to_target);
-  // Only an EMPTY cell can be contested (a target cell admits its owner alone): max-join.
-  if (mover && to_empty) atomicMax(&board[Q], head);
-  wave_lds_fence();
-  if (mover && (to_target || board[Q] == head)) {
-    board[Q] = head;  // overwrites the own target on arrival (move_agent)
-    board[P] = head - 1u;
-    ag.r += dr;
-    ag.c += dc;
-  }
-  wave_lds_fence();
-  step_count += 1;
-
-  const bool connected = is_agent && ag.r == ag.tr && ag.c == ag.tc;
-  // DenseRewardFn
-  const float rew = __fadd_rn(a.p.connected_reward * (float)(!was_connected && connected),
-                              a.p.timestep_reward * (float)(!was_connected));
-  const uint32_t bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
-  const bool done = connected || (bits >> 1) == 0u;  // connected_or_blocked
-  const bool all_done = __ballot(is_agent && !done) == 0ull;
-  const bool last = all_done || step_count >= a.p.time_limit;
-
-  if (is_agent) {
-    if (a.ts.reward) a.ts.reward[(size_t)b * N + lane] = rew;
-    if (a.ts.discount) a.ts.discount[(size_t)b * N + lane] = (last || done) ? 0.0f : 1.0f;
-  }
-  if (lane == 0 && a.ts.step_type) a.ts.step_type[b] = last ? 2 : 1;
-  write_extras(board, g, N, b, lane, ag, a.ts);
-
-  if (last && a.p.auto_reset) {
-    // VmapAutoResetWrapper._auto_reset: key, _ = split(state.key); state, ts = reset(key);
-    // only the observation of the terminal timestep is replaced.
-    Key2 sk;
-    sk.a = a.in.key[2 * (size_t)b];
-    sk.b = a.in.key[2 * (size_t)b + 1];
-    Key2 rk, unused;
-    split2_lanes(SubWave<64>(lane), sk, rk, unused);
-    generate_state(board, W, g, N, b, lane, rk, a.out, ag);
-    write_observation(board, g, N, b, lane, ag, 0, a.ts);
-    return;
-  }
-
-  // ---- store the stepped state and its observation -------------------------------------------
-  store_grid<64, false>(board, g, lane, a.out.grid + (size_t)b * g.n);
-  store_agents(a.out, b, N, lane, ag, true);
+  store_state(board, g, N, b, lane, ag, step_count, key, a.out);
+  write_observation(board, g, N, b, lane, ag, step_count, a.ts);
   if (lane == 0) {
-    a.out.step_count[b] = step_count;
-    if (a.out.key != a.in.key) {
-      a.out.key[2 * (size_t)b] = a.in.key[2 * (size_t)b];
-      a.out.key[2 * (size_t)b + 1] = a.in.key[2 * (size_t)b + 1];
-    }
+    if (a.stats.episodes) a.stats.episodes[b] = episodes;
+    if (a.stats.connections_made) a.stats.connections_made[b] = conn_made;
+    if (a.stats.unconnected_agent_steps) a.stats.unconnected_agent_steps[b] = pen_steps;
+    if (a.stats.final_connections) a.stats.final_connections[b] = fin_conn;
+    if (a.stats.final_path_length) a.stats.final_path_length[b] = fin_plen;
   }
-  store_mask(a.ts, b, N, lane, bits);
-  if (a.ts.obs_grid) store_obs(board, g, N, lane, a.ts.obs_grid + (size_t)b * N * g.n);
-  if (a.ts.obs_step_count && lane == 0) a.ts.obs_step_count[b] = step_count;
 }
 
 // split(key, num) for one key: thread t writes child t
@@ -492,23 +317,12 @@ __global__ void random_actions_kernel(const uint32_t *__restrict__ keys, int B, 
   if (idx >= (size_t)B * N) return;
   const size_t b = idx / N;
   const uint32_t i = (uint32_t)(idx - b * N);
-  Key2 kt;
-  threefry(keys[2 * b], keys[2 * b + 1], 0u, t, kt.a, kt.b);  // fold_in(key, t)
-  const uint32_t bits = random_bits_word(kt, i, (uint32_t)N);
+  const Key2 k = {keys[2 * b], keys[2 * b + 1]};
   const uint8_t *mk = mask + idx * 5;
-  int cnt = 0;
+  uint32_t bits = 0u;
 #pragma unroll
-  for (int a = 0; a < 5; ++a) cnt += mk[a] != 0;
-  const int pick = (int)(bits % (uint32_t)(cnt > 0 ? cnt : 1));
-  int chosen = 0, seen = 0;
-#pragma unroll
-  for (int a = 0; a < 5; ++a) {
-    if (mk[a]) {
-      if (seen == pick) chosen = a;
-      ++seen;
-    }
-  }
-  action[idx] = chosen;
+  for (int a = 0; a < 5; ++a) bits |= (uint32_t)(mk[a] != 0) << a;
+  action[idx] = random_policy_action(k, t, i, bits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -714,6 +528,39 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
   a.B = B; a.N = N; a.in = to_ptrs(state_in); a.out = to_ptrs(state_out); a.action = action;
   a.p = *params; a.ts = to_ptrs(timestep); a.mode = 2;
   return launch_env(a, stream, "rbg_connector_step");
+}
+
+int rbg_connector_rollout(int B, int m, int N, const rbg_state *state_in,
+                          const rbg_state *state_out, const uint32_t *policy_keys, uint32_t t0,
+                          int n_steps, const rbg_env_params *params,
+                          const rbg_rollout_stats *stats, const rbg_timestep *last_timestep,
+                          void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_rollout: B < 0");
+  if (n_steps < 1) return fail(RBG_E_PARAM, "rbg_connector_rollout: n_steps < 1");
+  if (!params) return fail(RBG_E_NULL, "rbg_connector_rollout: NULL params");
+  if (params->time_limit < 1) return fail(RBG_E_PARAM, "rbg_connector_rollout: time_limit < 1");
+  RolloutArgs a;
+  memset(&a, 0, sizeof(a));
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (B == 0) return 0;
+  if (!policy_keys) return fail(RBG_E_NULL, "rbg_connector_rollout: NULL policy_keys");
+  if (!state_complete(state_in) || !state_complete(state_out))
+    return fail(RBG_E_NULL, "rbg_connector_rollout: incomplete state");
+  if (int rc = check_align(a.g, state_in->grid, state_out->grid,
+                           last_timestep ? last_timestep->obs_grid : nullptr))
+    return rc;
+  a.B = B; a.N = N; a.in = to_ptrs(state_in); a.out = to_ptrs(state_out);
+  a.policy_keys = policy_keys; a.t0 = t0; a.n_steps = n_steps; a.p = *params;
+  if (stats) {
+    RolloutStatsPtrs sp = {stats->episodes, stats->connections_made,
+                           stats->unconnected_agent_steps, stats->final_connections,
+                           stats->final_path_length};
+    a.stats = sp;
+  }
+  if (last_timestep) a.ts = to_ptrs(last_timestep);
+  hipLaunchKernelGGL(connector_rollout_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
+                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  return check_hip(hipGetLastError(), "rbg_connector_rollout");
 }
 
 int rbg_random_actions(const uint32_t *keys, int B, int N, uint32_t t, const uint8_t *action_mask,

@@ -1,0 +1,315 @@
+// rbg_env.h -- Connector environment pieces on an LDS-resident env (one env per wavefront):
+// state load/store, action mask, observation, extras, one step, regeneration.
+// Semantics: [3P] jumanji==0.2.2 jumanji/environments/routing/connector/{env,utils,reward}.py and
+// jumanji/wrappers.py (see DESIGN.md section 2 for what is pinned and what is project-defined).
+#pragma once
+#include "../../include/rbg_prw.h"
+#include "rbg_device.h"
+#include "rbg_walk.h"
+
+namespace rbg {
+
+// HBM int32 grid -> padded LDS board
+__device__ __forceinline__ void load_grid(uint32_t *board, const Geo &g, int lane,
+                                          const int32_t *__restrict__ in) {
+  for (int w = lane; w < g.words; w += kWaveSize) board[w] = kWall;
+  wave_lds_fence();
+  if ((g.m & 3) == 0) {
+    for (int idx = lane * 4; idx < g.n; idx += kWaveSize * 4) {
+      const int r = div_m(g, idx);
+      const int4 v = *reinterpret_cast<const int4 *>(&in[idx]);
+      *reinterpret_cast<uint4 *>(&board[pad_index(g, r, idx - r * g.m)]) =
+          make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+    }
+  } else {
+    for (int idx = lane; idx < g.n; idx += kWaveSize) {
+      const int r = div_m(g, idx);
+      board[pad_index(g, r, idx - r * g.m)] = (uint32_t)in[idx];
+    }
+  }
+  wave_lds_fence();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Connector observation pieces ([3P] jumanji connector/env.py)
+// ---------------------------------------------------------------------------------------------
+struct AgentRegs {
+  int r0, c0;  // start
+  int tr, tc;  // target
+  int r, c;    // position
+};
+
+// _get_action_mask: bits 0..4 = NOOP, UP, RIGHT, DOWN, LEFT
+__device__ __forceinline__ uint32_t action_mask_bits(const uint32_t *board, const Geo &g,
+                                                     const AgentRegs &a, int lane) {
+  const bool connected = a.r == a.tr && a.c == a.tc;
+  const int P = pad_index(g, a.r, a.c);
+  const uint32_t tgt = 3u * (uint32_t)lane + 3u;
+  const uint32_t vu = board[P - g.S], vr = board[P + 1], vd = board[P + g.S], vl = board[P - 1];
+  uint32_t bits = 1u;
+  if (!connected) {
+    bits |= (uint32_t)(vu == 0u || vu == tgt) << 1;
+    bits |= (uint32_t)(vr == 0u || vr == tgt) << 2;
+    bits |= (uint32_t)(vd == 0u || vd == tgt) << 3;
+    bits |= (uint32_t)(vl == 0u || vl == tgt) << 4;
+  }
+  return bits;
+}
+
+// _obs_from_grid: agent i sees v > 0 as ((v - 1 - 3 i) mod 3N) + 1 (own cells become 1, 2, 3)
+__device__ __forceinline__ int obs_value(uint32_t v, int i3, int n3) {
+  int t = (int)v - 1 - i3;
+  t += t < 0 ? n3 : 0;
+  return v == 0u ? 0 : t + 1;
+}
+
+__device__ __forceinline__ void store_obs(const uint32_t *board, const Geo &g, int N, int lane,
+                                          int32_t *__restrict__ obs) {
+  const int n3 = 3 * N;
+  if ((g.m & 3) == 0) {
+    for (int idx = lane * 4; idx < g.n; idx += kWaveSize * 4) {
+      const int r = div_m(g, idx);
+      const uint4 v = *reinterpret_cast<const uint4 *>(&board[pad_index(g, r, idx - r * g.m)]);
+      for (int i = 0; i < N; ++i) {
+        int4 o;
+        o.x = obs_value(v.x, 3 * i, n3);
+        o.y = obs_value(v.y, 3 * i, n3);
+        o.z = obs_value(v.z, 3 * i, n3);
+        o.w = obs_value(v.w, 3 * i, n3);
+        *reinterpret_cast<int4 *>(&obs[(size_t)i * g.n + idx]) = o;
+      }
+    }
+  } else {
+    for (int idx = lane; idx < g.n; idx += kWaveSize) {
+      const int r = div_m(g, idx);
+      const uint32_t v = board[pad_index(g, r, idx - r * g.m)];
+      for (int i = 0; i < N; ++i) obs[(size_t)i * g.n + idx] = obs_value(v, 3 * i, n3);
+    }
+  }
+}
+
+// number of PATH cells (v % 3 == 1), the `total_path_length` extra
+__device__ __forceinline__ int count_path_cells(const uint32_t *board, const Geo &g, int lane) {
+  int cnt = 0;
+  for (int idx = lane; idx < g.n; idx += kWaveSize) {
+    const int r = div_m(g, idx);
+    cnt += (int)(board[pad_index(g, r, idx - r * g.m)] % 3u == 1u);
+  }
+  return SubWave<64>(lane).sum_i32(cnt);
+}
+
+struct TimestepPtrs {
+  int8_t *step_type;
+  float *reward;
+  float *discount;
+  int32_t *obs_grid;
+  uint8_t *action_mask;
+  int32_t *obs_step_count;
+  int32_t *num_connections;
+  float *ratio_connections;
+  int32_t *total_path_length;
+};
+struct StatePtrs {
+  int32_t *grid;
+  int32_t *step_count;
+  int32_t *start;
+  int32_t *target;
+  int32_t *position;
+  uint32_t *key;
+};
+
+__device__ __forceinline__ void store_mask(const TimestepPtrs &ts, int b, int N, int lane,
+                                           uint32_t bits) {
+  if (ts.action_mask && lane < N) {
+    uint8_t *p = ts.action_mask + ((size_t)b * N + lane) * 5;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) p[a] = (uint8_t)((bits >> a) & 1u);
+  }
+}
+
+__device__ __forceinline__ void store_agents(const StatePtrs &st, int b, int N, int lane,
+                                             const AgentRegs &a, bool with_start_target) {
+  if (lane < N) {
+    const size_t o = ((size_t)b * N + lane) * 2;
+    if (with_start_target) {
+      *reinterpret_cast<int2 *>(&st.start[o]) = make_int2(a.r0, a.c0);
+      *reinterpret_cast<int2 *>(&st.target[o]) = make_int2(a.tr, a.tc);
+    }
+    *reinterpret_cast<int2 *>(&st.position[o]) = make_int2(a.r, a.c);
+  }
+}
+
+// Builds a fresh State from a finished walk (parallel_random_walk_generator.py:58-77) and turns
+// the LDS board into the training grid (heads + targets only).
+__device__ __forceinline__ void board_to_training(uint32_t *board, const Geo &g, int lane) {
+  for (int idx = lane; idx < g.n; idx += kWaveSize) {
+    const int r = div_m(g, idx);
+    const int p = pad_index(g, r, idx - r * g.m);
+    const uint32_t v = board[p];
+    if (v % 3u == 1u) board[p] = 0u;
+  }
+  wave_lds_fence();
+}
+
+// Observation + extras of the state held in (board, ag); `terminal` keeps reward/discount/
+// step_type/extras of the step that just ended when the env was auto-reset.
+__device__ __forceinline__ void write_observation(const uint32_t *board, const Geo &g, int N,
+                                                  int b, int lane, const AgentRegs &ag,
+                                                  int step_count, const TimestepPtrs &ts) {
+  const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
+  store_mask(ts, b, N, lane, bits);
+  if (ts.obs_grid) store_obs(board, g, N, lane, ts.obs_grid + (size_t)b * N * g.n);
+  if (ts.obs_step_count && lane == 0) ts.obs_step_count[b] = step_count;
+}
+
+__device__ __forceinline__ void write_extras(const uint32_t *board, const Geo &g, int N, int b,
+                                             int lane, const AgentRegs &ag,
+                                             const TimestepPtrs &ts) {
+  const bool connected = lane < N && ag.r == ag.tr && ag.c == ag.tc;
+  const int conn = __popcll(__ballot(connected));
+  const int plen = ts.total_path_length ? count_path_cells(board, g, lane) : 0;
+  if (lane == 0) {
+    if (ts.num_connections) ts.num_connections[b] = conn;
+    if (ts.ratio_connections) ts.ratio_connections[b] = __fdiv_rn((float)conn, (float)N);
+    if (ts.total_path_length) ts.total_path_length[b] = plen;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One Connector.step on the LDS-resident env ([3P] env.py::step / _step_agents / _step_agent).
+// ---------------------------------------------------------------------------------------------
+struct StepResult {
+  bool was_connected, connected, done;  // per agent lane
+  bool last;                            // wave-uniform: all done or time limit reached
+  uint32_t bits;                        // action mask of the stepped state
+};
+
+// _step_agent: move iff the action is not NOOP, the destination is in bounds and empty or the
+// agent's own target, and the agent is not connected yet.  Only an EMPTY cell can be contested
+// (a target cell admits its owner alone): max-join through one ds_max_u32, losers stay.
+__device__ __forceinline__ StepResult env_step_core(uint32_t *board, const Geo &g, int N, int lane,
+                                                    AgentRegs &ag, int &step_count, int act,
+                                                    int time_limit) {
+  const bool is_agent = lane < N;
+  const uint32_t head = 3u * (uint32_t)lane + 2u;
+  StepResult res;
+  res.was_connected = is_agent && ag.r == ag.tr && ag.c == ag.tc;
+  act = act < 0 ? 0 : act > 4 ? 4 : act;  // lax.switch clamps its index (move_position)
+  const int dr = act == 1 ? -1 : act == 3 ? 1 : 0;
+  const int dc = act == 2 ? 1 : act == 4 ? -1 : 0;
+  const int P = pad_index(g, ag.r, ag.c);
+  const int Q = P + dr * g.S + dc;
+  const uint32_t vq = board[Q];
+  const bool to_empty = vq == 0u;
+  const bool to_target = vq == head + 1u;
+  const bool mover = is_agent && act != 0 && !res.was_connected && (to_empty || to_target);
+  if (mover && to_empty) atomicMax(&board[Q], head);
+  wave_lds_fence();
+  if (mover && (to_target || board[Q] == head)) {
+    board[Q] = head;  // overwrites the own target on arrival (move_agent)
+    board[P] = head - 1u;
+    ag.r += dr;
+    ag.c += dc;
+  }
+  wave_lds_fence();
+  step_count += 1;
+  res.connected = is_agent && ag.r == ag.tr && ag.c == ag.tc;
+  res.bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
+  res.done = res.connected || (res.bits >> 1) == 0u;  // connected_or_blocked
+  const bool all_done = __ballot(is_agent && !res.done) == 0ull;
+  res.last = all_done || step_count >= time_limit;
+  return res;
+}
+
+// DenseRewardFn
+__device__ __forceinline__ float dense_reward(const StepResult &r, const rbg_env_params &p) {
+  return __fadd_rn(p.connected_reward * (float)(!r.was_connected && r.connected),
+                   p.timestep_reward * (float)(!r.was_connected));
+}
+
+// Generator -> State in LDS/registers only: runs the walk for `key_in` (the generator's
+// argument), leaves the training grid in LDS, fills the agent registers, returns State.key.
+__device__ __forceinline__ Key2 regenerate(uint32_t *board, uint32_t *W, const Geo &g, int N,
+                                           int lane, Key2 key_in, AgentRegs &ag) {
+  const SubWave<64> sw(lane);
+  Key2 key, unused;
+  split2_lanes(sw, key_in, key, unused);
+  Walker w;
+  prw_walk_full(sw, board, W, g, N, key, w);
+  board_to_training(board, g, lane);
+  ag.r0 = w.r0; ag.c0 = w.c0;
+  ag.tr = w.r;  ag.tc = w.c;
+  ag.r = w.r0;  ag.c = w.c0;
+  return key;
+}
+
+// State (LDS board + registers) -> HBM
+__device__ __forceinline__ void store_state(const uint32_t *board, const Geo &g, int N, int b,
+                                            int lane, const AgentRegs &ag, int step_count,
+                                            Key2 key, const StatePtrs &out) {
+  store_grid<64, false>(board, g, lane, out.grid + (size_t)b * g.n);
+  store_agents(out, b, N, lane, ag, true);
+  if (lane == 0) {
+    out.step_count[b] = step_count;
+    *reinterpret_cast<uint2 *>(&out.key[2 * (size_t)b]) = make_uint2(key.a, key.b);
+  }
+}
+
+// HBM -> State (LDS board + registers)
+__device__ __forceinline__ void load_state(uint32_t *board, const Geo &g, int N, int b, int lane,
+                                           const StatePtrs &in, AgentRegs &ag, int &step_count,
+                                           Key2 &key) {
+  load_grid(board, g, lane, in.grid + (size_t)b * g.n);
+  if (lane < N) {
+    const size_t o = ((size_t)b * N + lane) * 2;
+    const int2 s = *reinterpret_cast<const int2 *>(&in.start[o]);
+    const int2 t = *reinterpret_cast<const int2 *>(&in.target[o]);
+    const int2 p = *reinterpret_cast<const int2 *>(&in.position[o]);
+    ag.r0 = s.x; ag.c0 = s.y; ag.tr = t.x; ag.tc = t.y; ag.r = p.x; ag.c = p.y;
+  }
+  step_count = in.step_count[b];
+  key.a = in.key[2 * (size_t)b];
+  key.b = in.key[2 * (size_t)b + 1];
+}
+
+// reward/discount/step_type of a restart timestep
+__device__ __forceinline__ void write_restart(int N, int b, int lane, const TimestepPtrs &ts) {
+  if (lane < N) {
+    if (ts.reward) ts.reward[(size_t)b * N + lane] = 0.0f;
+    if (ts.discount) ts.discount[(size_t)b * N + lane] = 1.0f;
+  }
+  if (lane == 0 && ts.step_type) ts.step_type[b] = 0;
+}
+
+// reward/discount/step_type of a stepped timestep
+__device__ __forceinline__ void write_step_outcome(const StepResult &res, const rbg_env_params &p,
+                                                   int N, int b, int lane,
+                                                   const TimestepPtrs &ts) {
+  if (lane < N) {
+    if (ts.reward) ts.reward[(size_t)b * N + lane] = dense_reward(res, p);
+    if (ts.discount) ts.discount[(size_t)b * N + lane] = (res.last || res.done) ? 0.0f : 1.0f;
+  }
+  if (lane == 0 && ts.step_type) ts.step_type[b] = res.last ? 2 : 1;
+}
+
+// masked-uniform random policy (defined by this project; include/rbg_prw.h): agent i of an env
+// with policy key k picks, at global step t, legal action number
+//   threefry2x32(k, (t, i)).y0 mod #legal   (legal actions in ascending order).
+__device__ __forceinline__ int random_policy_action(Key2 k, uint32_t t, uint32_t i,
+                                                    uint32_t mask_bits) {
+  uint32_t y0, y1;
+  threefry(k.a, k.b, t, i, y0, y1);
+  const int cnt = __popc(mask_bits & 31u);
+  const int pick = (int)(y0 % (uint32_t)(cnt > 0 ? cnt : 1));
+  int chosen = 0, seen = 0;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    if ((mask_bits >> a) & 1u) {
+      if (seen == pick) chosen = a;
+      ++seen;
+    }
+  }
+  return chosen;
+}
+
+}  // namespace rbg

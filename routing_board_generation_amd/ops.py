@@ -217,6 +217,43 @@ def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
     return so, ts
 
 
+ROLLOUT_STATS = ("episodes", "connections_made", "unconnected_agent_steps", "final_connections",
+                 "final_path_length")
+
+
+def connector_rollout(state: StateBufs, policy_keys: torch.Tensor, t0: int, n_steps: int,
+                      time_limit: int = 50, timestep_reward: float = -0.03,
+                      connected_reward: float = 0.1, auto_reset: bool = True,
+                      state_out: Optional[StateBufs] = None, stats: Optional[dict] = None,
+                      timestep: Optional[TimestepBufs] = None, want_timestep: bool = False):
+    """n_steps of random-policy stepping in one launch.  Returns (state_out, stats, timestep);
+    timestep is None unless a buffer dict is passed or want_timestep is set."""
+    B, m, _ = state["grid"].shape
+    N = state["start"].shape[1]
+    dev = state["grid"].device
+    policy_keys = check_keys(policy_keys)
+    if policy_keys.shape[0] != B:
+        raise ValueError("policy_keys and state disagree on B")
+    so = state_out if state_out is not None else alloc_state(B, m, N, dev)
+    st = stats if stats is not None else {k: torch.empty((B,), dtype=torch.int32, device=dev)
+                                          for k in ROLLOUT_STATS}
+    for k in ROLLOUT_STATS:
+        if k in st:
+            _check(st[k], torch.int32, (B,), f"stats.{k}")
+    ts = timestep if timestep is not None else (alloc_timestep(B, m, N, dev) if want_timestep
+                                                else None)
+    si, s_o = _state_struct(state, B, m, N), _state_struct(so, B, m, N)
+    sp = nat.RolloutStats(*[_ptr(st.get(k)) for k in ROLLOUT_STATS])
+    p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
+                      int(bool(auto_reset)))
+    tp = _timestep_struct(ts, B, m, N) if ts is not None else None
+    nat.check(nat.lib().rbg_connector_rollout(
+        B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(), int(t0) & 0xFFFFFFFF,
+        int(n_steps), C.byref(p), C.byref(sp), C.byref(tp) if tp is not None else None,
+        _stream(dev)), "rbg_connector_rollout")
+    return so, st, ts
+
+
 def random_actions(keys: torch.Tensor, t: int, action_mask: torch.Tensor,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     keys = check_keys(keys)
