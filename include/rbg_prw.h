@@ -137,7 +137,8 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
 /* Masked-uniform random policy over the legal set (defined by this project; stands in for
  * [3P] jumanji.training.agents.random.RandomAgent in the rollout benchmark, BASELINE config 3):
  * at global step t, agent i of env b picks legal action number
- *   threefry2x32(keys[b], counter (t, i)).y0 mod #legal     (legal actions in ascending order). */
+ *   floor(threefry2x32(keys[b], counter (t, i)).y0 * #legal / 2^32)
+ * (legal actions in ascending order; NOOP is always legal). */
 int rbg_random_actions(const uint32_t *keys, int B, int N, uint32_t t, const uint8_t *action_mask,
                        int32_t *action, void *stream);
 

@@ -736,8 +736,8 @@ int oracle_connector_step_batch(int B, int m, int N, int32_t *grid, int32_t *ste
 
 /* Masked-uniform random policy "defined by this project" (the reference's RandomAgent lives in
  * jumanji.training and draws a Gumbel categorical; nothing pins it).  At global step t, agent i of
- * env b picks legal action number threefry2x32(key_b, counter (t, i)).y0 mod #legal, legal actions
- * in ascending order. */
+ * env b picks legal action number floor(threefry2x32(key_b, counter (t, i)).y0 * #legal / 2^32),
+ * legal actions in ascending order. */
 void oracle_random_actions_batch(const uint32_t *keys /*[B][2]*/, int B, int N, uint32_t t,
                                  const uint8_t *action_mask /*[B][N][5]*/,
                                  int32_t *action /*[B][N]*/) {
@@ -748,7 +748,7 @@ void oracle_random_actions_batch(const uint32_t *keys /*[B][2]*/, int B, int N, 
       oracle_threefry2x32(keys[2 * b], keys[2 * b + 1], t, (uint32_t)i, &y0, &y1);
       int cnt = 0;
       for (int a = 0; a < 5; ++a) cnt += mk[a] != 0;
-      int pick = (int)(y0 % (uint32_t)(cnt > 0 ? cnt : 1)), a = 0, chosen = 0;
+      int pick = (int)(((uint64_t)y0 * (uint64_t)cnt) >> 32), a = 0, chosen = 0;
       for (a = 0; a < 5; ++a)
         if (mk[a] && pick-- == 0) {
           chosen = a;

@@ -294,13 +294,13 @@ __device__ __forceinline__ void write_step_outcome(const StepResult &res, const 
 
 // masked-uniform random policy (defined by this project; include/rbg_prw.h): agent i of an env
 // with policy key k picks, at global step t, legal action number
-//   threefry2x32(k, (t, i)).y0 mod #legal   (legal actions in ascending order).
+//   floor(threefry2x32(k, (t, i)).y0 * #legal / 2^32)   (legal actions in ascending order).
 __device__ __forceinline__ int random_policy_action(Key2 k, uint32_t t, uint32_t i,
                                                     uint32_t mask_bits) {
   uint32_t y0, y1;
   threefry(k.a, k.b, t, i, y0, y1);
   const int cnt = __popc(mask_bits & 31u);
-  const int pick = (int)(y0 % (uint32_t)(cnt > 0 ? cnt : 1));
+  const int pick = (int)__umulhi(y0, (uint32_t)cnt);
   int chosen = 0, seen = 0;
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
