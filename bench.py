@@ -59,8 +59,11 @@ def measured_traffic(kernel: str, boards: int):
                    key=os.path.getmtime)
     if not files or boards != BATCH_PER_GPU:
         return None
-    rec = json.load(open(files[-1]))["kernels"].get(kernel)
-    return rec["hbm_bytes_per_launch"] if rec else None
+    kernels = json.load(open(files[-1]))["kernels"]
+    for name, rec in kernels.items():  # template instances are listed as name<...>
+        if name == kernel or name.startswith(kernel + "<"):
+            return rec["hbm_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(sample_batches: int):
@@ -158,7 +161,8 @@ def main() -> None:
 
     bpb = generator_bytes_per_board(m, N)
     achieved = B * bpb / (kernel_avg_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "prw_generate_kernel", "achieved": achieved,
+    roofline = {"bound": "hbm", "kernel": "prw_generate_kernel<32> (2 boards per wavefront)",
+                "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic("prw_generate_kernel", B),
                 "algorithmic_bytes_per_launch": B * bpb,
