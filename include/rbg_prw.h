@@ -112,6 +112,15 @@ int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
 int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *train_grid,
                          int32_t *start, int32_t *target, uint32_t *key_out, void *stream);
 
+/* vmap(BoardDatasetGeneratorJAX.__call__)(keys): sample one of `n_boards` pre-generated boards
+ *   routing_board_generation/rl_training/offline_generation/dataset_generator_jax.py:112-141
+ * (the dataset itself, :57-110, is rbg_split + rbg_prw_generate(split_first=0) over
+ * split(PRNGKey(0), n_boards)).  heads/targets int32 [n_boards][N][2] (agent-major);
+ * which (nullable) int32 [B] = the sampled board index ([3P] jax.random.randint semantics). */
+int rbg_dataset_sample(const uint32_t *keys, int B, int m, int N, int n_boards,
+                       const int32_t *heads, const int32_t *targets, const rbg_state *state,
+                       int32_t *which, void *stream);
+
 /* ---- Connector environment ([3P] jumanji/environments/routing/connector/env.py) ----------- */
 
 /* vmap(Connector(generator=ParallelRandomWalkGenerator(m, N)).reset)(keys)

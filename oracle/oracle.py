@@ -331,3 +331,37 @@ def connector_rollout_batch(st, policy_keys, t0, n_steps, time_limit=50, timeste
         stats["final_path_length"] += np.where(last, ts["total_path_length"], 0).astype(np.int32)
         mask = ts["action_mask"]
     return stats, ts
+
+
+def randint(key, lo, hi):
+    """[3P] jax.random.randint(key, (), lo, hi) (jax/_src/random.py::_randint), 32-bit path."""
+    k = split(key, 2)
+    hi_bits = int(random_bits(k[0], 1)[0])
+    lo_bits = int(random_bits(k[1], 1)[0])
+    span = (hi - lo) & 0xFFFFFFFF
+    span = 1 if hi <= lo else span
+    mult = (65536 % span)
+    mult = ((mult * mult) & 0xFFFFFFFF) % span
+    off = (((hi_bits % span) * mult) & 0xFFFFFFFF) + (lo_bits % span)
+    return lo + ((off & 0xFFFFFFFF) % span)
+
+
+def dataset_sample_batch(keys, heads, targets, m):
+    """BoardDatasetGeneratorJAX.__call__ vmapped: -> (state dict, which [B])."""
+    keys = _u32(keys).reshape(-1, 2)
+    B, N = keys.shape[0], heads.shape[1]
+    st = alloc_state(B, m, N)
+    which = np.zeros((B,), np.int32)
+    for b in range(B):
+        k0 = split(keys[b])[0]
+        w = randint(k0, 0, heads.shape[0])
+        which[b] = w
+        st["key"][b] = k0
+        st["start"][b] = heads[w]
+        st["target"][b] = targets[w]
+        st["position"][b] = heads[w]
+        for i in range(N):
+            st["grid"][b, heads[w, i, 0], heads[w, i, 1]] = 2 + 3 * i
+        for i in range(N):
+            st["grid"][b, targets[w, i, 0], targets[w, i, 1]] = 3 + 3 * i
+    return st, which

@@ -9,6 +9,7 @@ from .board_generation.parallel_random_walk import ParallelRandomWalkBoard  # no
 from .connector import (Connector, DenseRewardFn, MultiToSingleWrapper,  # noqa: F401
                         VmapAutoResetWrapper)
 from .interface.board_generator_interface import BoardGenerator, BoardName  # noqa: F401
+from .offline_generation import BoardDatasetGenerator  # noqa: F401
 from .online_generators import (Generator, ParallelRandomWalkGenerator,  # noqa: F401
                                 UniformRandomGenerator)
 from .random import PRNGKey, split  # noqa: F401

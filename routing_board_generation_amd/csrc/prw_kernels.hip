@@ -289,6 +289,54 @@ __global__ __launch_bounds__(kBlock) void connector_rollout_kernel(RolloutArgs a
   }
 }
 
+// BoardDatasetGeneratorJAX.__call__ (rl_training/offline_generation/dataset_generator_jax.py
+// :112-141): key, _ = split(key); which = randint(key, (), 0, n_boards); State from the stored
+// heads/targets of board `which`.  [3P] jax/_src/random.py::_randint: k1, k2 = split(key);
+// hi, lo = random_bits(k1), random_bits(k2); offset = ((hi % span) * mult + lo % span) % span in
+// wrapping uint32 arithmetic, mult = ((2^16 % span)^2) % span (host-computed).
+struct DatasetArgs {
+  const uint32_t *keys;
+  int B, N, n_boards;
+  uint32_t mult;
+  Geo g;
+  const int32_t *heads;    // [n_boards][N][2]
+  const int32_t *targets;  // [n_boards][N][2]
+  StatePtrs out;
+  int32_t *which;
+};
+
+__global__ __launch_bounds__(kBlock) void dataset_sample_kernel(DatasetArgs a) {
+  const int lane = threadIdx.x & (kWaveSize - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * kWavesPerBlock + wib;
+  if (b >= a.B) return;
+  const SubWave<64> sw(lane);
+  const Geo g = a.g;
+  uint32_t *board = g_lds + wib * slab_words<64>(g);
+  Key2 key, k0, unused, k1, k2;
+  key.a = a.keys[2 * (size_t)b];
+  key.b = a.keys[2 * (size_t)b + 1];
+  split2_lanes(sw, key, k0, unused);
+  split2_lanes(sw, k0, k1, k2);
+  const uint2 hi = threefry_call(k1.a, k1.b, 0u, 0u), lo = threefry_call(k2.a, k2.b, 0u, 0u);
+  const uint32_t span = (uint32_t)a.n_boards;
+  const uint32_t which = ((hi.x % span) * a.mult + (lo.x % span)) % span;
+  board_clear<64>(board, g, lane);
+  AgentRegs ag = {0, 0, 0, 0, 0, 0};
+  if (lane < a.N) {
+    const size_t o = ((size_t)which * a.N + lane) * 2;
+    const int2 h = *reinterpret_cast<const int2 *>(&a.heads[o]);
+    const int2 t = *reinterpret_cast<const int2 *>(&a.targets[o]);
+    ag.r0 = ag.r = h.x; ag.c0 = ag.c = h.y; ag.tr = t.x; ag.tc = t.y;
+    board[pad_index(g, h.x, h.y)] = 3u * lane + 2u;
+  }
+  wave_lds_fence();
+  if (lane < a.N) board[pad_index(g, ag.tr, ag.tc)] = 3u * lane + 3u;  // targets written last
+  wave_lds_fence();
+  store_state(board, g, a.N, b, lane, ag, 0, k0, a.out);
+  if (lane == 0 && a.which) a.which[b] = (int32_t)which;
+}
+
 // split(key, num) for one key: thread t writes child t
 __global__ void split_kernel(uint32_t k0, uint32_t k1, int num, uint32_t *__restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -561,6 +609,28 @@ int rbg_connector_rollout(int B, int m, int N, const rbg_state *state_in,
   hipLaunchKernelGGL(connector_rollout_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
                      dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
   return check_hip(hipGetLastError(), "rbg_connector_rollout");
+}
+
+int rbg_dataset_sample(const uint32_t *keys, int B, int m, int N, int n_boards,
+                       const int32_t *heads, const int32_t *targets, const rbg_state *state,
+                       int32_t *which, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_dataset_sample: B < 0");
+  if (n_boards < 1) return fail(RBG_E_SHAPE, "rbg_dataset_sample: n_boards < 1");
+  DatasetArgs a;
+  memset(&a, 0, sizeof(a));
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (B == 0) return 0;
+  if (!keys || !heads || !targets) return fail(RBG_E_NULL, "rbg_dataset_sample: NULL pointer");
+  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_dataset_sample: incomplete state");
+  if (int rc = check_align(a.g, state->grid, nullptr, nullptr)) return rc;
+  const uint32_t span = (uint32_t)n_boards;
+  const uint32_t m16 = 65536u % span;
+  a.mult = (uint32_t)(m16 * m16) % span;  // wrapping uint32 arithmetic, as in jax's _randint
+  a.keys = keys; a.B = B; a.N = N; a.n_boards = n_boards; a.heads = heads; a.targets = targets;
+  a.out = to_ptrs(state); a.which = which;
+  hipLaunchKernelGGL(dataset_sample_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
+                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  return check_hip(hipGetLastError(), "rbg_dataset_sample");
 }
 
 int rbg_random_actions(const uint32_t *keys, int B, int N, uint32_t t, const uint8_t *action_mask,

@@ -42,11 +42,16 @@ class BoardGenerator:
                 "(only 'offline_parallel_rw' is implemented natively)") from None
 
 
-def make_online_generator(generation_type: str, grid_size: int, num_agents: int):
-    """The `online_*` branch of setup_train._make_raw_env
-    (routing_board_generation/rl_training/setup_train.py:131-152)."""
+def make_online_generator(generation_type: str, grid_size: int, num_agents: int, **kwargs):
+    """The generator dispatch of setup_train._make_raw_env
+    (routing_board_generation/rl_training/setup_train.py:112-152) for the generation types this
+    package implements; kwargs (number_of_boards) go to the offline dataset generator."""
+    from ..offline_generation import BoardDatasetGenerator
     from ..online_generators import ParallelRandomWalkGenerator, UniformRandomGenerator
 
+    if generation_type == "offline_parallel_rw":
+        return BoardDatasetGenerator(grid_size=grid_size, num_agents=num_agents,
+                                     board_name=generation_type, **kwargs)
     if generation_type == "online_parallel_rw":
         return ParallelRandomWalkGenerator(grid_size=grid_size, num_agents=num_agents)
     if generation_type == "online_uniform":

@@ -172,6 +172,23 @@ def uniform_generate(keys: torch.Tensor, m: int, N: int) -> StateBufs:
     return st
 
 
+def dataset_sample(keys: torch.Tensor, heads: torch.Tensor, targets: torch.Tensor, m: int,
+                   want_which: bool = False):
+    """Sample boards of a pre-generated dataset (heads/targets [n_boards, N, 2]) -> state bufs."""
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    n_boards, N, _ = heads.shape
+    _check(heads, torch.int32, (n_boards, N, 2), "heads")
+    _check(targets, torch.int32, (n_boards, N, 2), "targets")
+    st = alloc_state(B, m, N, dev)
+    which = torch.empty((B,), dtype=torch.int32, device=dev) if want_which else None
+    s = _state_struct(st, B, m, N)
+    nat.check(nat.lib().rbg_dataset_sample(keys.data_ptr(), B, m, N, n_boards, heads.data_ptr(),
+                                           targets.data_ptr(), C.byref(s), _ptr(which),
+                                           _stream(dev)), "rbg_dataset_sample")
+    return st, which
+
+
 # ------------------------------------------------------------------------------------- Connector
 def connector_reset(keys: torch.Tensor, m: int, N: int, state: Optional[StateBufs] = None,
                     timestep: Optional[TimestepBufs] = None):
