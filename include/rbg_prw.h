@@ -107,6 +107,17 @@ int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
                      int32_t *position, int32_t *step_count, uint32_t *key_out, int32_t *iters,
                      void *stream);
 
+/* vmap(SequentialRandomWalkBoard(m, m, N).generate)(keys)                   [split_first == 0]
+ *   JAXI/sequential_random_walk.py:322-431 (generate + generate_starts_ends)
+ * vmap(SequentialRandomWalkGenerator(m, N).__call__)(keys)                  [split_first != 0]
+ *   routing_board_generation/rl_training/online_generators/sequential_random_walk_generator.py:34-66
+ * Same outputs as rbg_prw_generate; attempts (nullable) int32 [B] = the retry that succeeded
+ * (1 .. 2m; 0 = every attempt failed: board all zero, all starts/targets (0, 0)).  m >= 3. */
+int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
+                        int32_t *solved_grid, int32_t *train_grid, int32_t *start,
+                        int32_t *target, int32_t *position, int32_t *step_count,
+                        uint32_t *key_out, int32_t *attempts, void *stream);
+
 /* vmap(UniformRandomGenerator(m, N).__call__)(keys)
  *   routing_board_generation/rl_training/online_generators/uniform_generator.py:70-109 */
 int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *train_grid,

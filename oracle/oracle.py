@@ -365,3 +365,17 @@ def dataset_sample_batch(keys, heads, targets, m):
         for i in range(N):
             st["grid"][b, targets[w, i, 0], targets[w, i, 1]] = 3 + 3 * i
     return st, which
+
+
+def seq_rw_generator_batch(keys, m, N, threads=1):
+    """SequentialRandomWalkGenerator.__call__ vmapped -> (state, solved [B,m,m], attempts [B])."""
+    keys = _u32(keys).reshape(-1, 2)
+    B = keys.shape[0]
+    st = alloc_state(B, m, N)
+    solved = np.zeros((B, m, m), np.int32)
+    attempts = np.zeros((B,), np.int32)
+    rc = lib().oracle_seq_rw_generator_batch(_p(keys), B, m, N, *[_p(st[k]) for k in _STATE_ORDER],
+                                             _p(solved), _p(attempts), threads)
+    if rc != 0:
+        raise ValueError("oracle_seq_rw_generator_batch: bad arguments")
+    return st, solved, attempts

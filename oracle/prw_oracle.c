@@ -758,3 +758,144 @@ void oracle_random_actions_batch(const uint32_t *keys /*[B][2]*/, int B, int N, 
     }
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * SequentialRandomWalkBoard (JAXI/sequential_random_walk.py) -- SURVEY.md 8f rank 3, pinned by
+ * the single-board golden of package_evaluation/profiling_generators.ipynb cell 7 (G7).
+ *
+ * choice(key, a, shape=(), replace=False, p=mask) is jax's Gumbel top-1:
+ *   g = -gumbel(key, (n,)) - log(p); argsort(g)[0]      ([3P] jax/_src/random.py::choice)
+ * gumbel is monotone in the uniform u, so the winner is the valid entry with the largest
+ * u = bits >> 9 (lowest index on ties), evaluated here on the integers.  (float32 rounding of
+ * log(-log(u)) could merge two adjacent u into one g and then prefer the lower index; that
+ * cannot be reproduced without XLA's exact log and is not attempted -- SURVEY Appendix A.6.)
+ * ---------------------------------------------------------------------------------------- */
+static int gumbel_top1(const uint32_t key[2], const uint8_t *valid, int n) {
+  uint32_t bits[ORACLE_MAX_CELLS];
+  oracle_random_bits(key, n, bits);
+  int best = 0, have = 0;
+  uint32_t best_u = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!valid[j]) continue;
+    uint32_t u = bits[j] >> 9;
+    if (!have || u > best_u) {
+      best = j;
+      best_u = u;
+      have = 1;
+    }
+  }
+  return best; /* all-invalid: argsort of all-inf keeps index 0 */
+}
+
+/* :138-140 available_cells: PRW's rule, padded to rows + 1 entries */
+static void seq_available(const int32_t *grid, int m, int32_t cell, int32_t *avail /*[m+1]*/) {
+  int32_t a4[4];
+  oracle_available_cells(grid, m, m, cell, a4);
+  for (int k = 0; k < m + 1; ++k) avail[k] = k < 4 ? a4[k] : -1;
+}
+
+/* add_agents (:290-320) for one max_length; returns success, fills first/last cell per wire */
+static int seq_add_agents(const uint32_t key_in[2], int m, int N, int max_length, int32_t *grid,
+                          int32_t *first /*[N]*/, int32_t *last /*[N]*/) {
+  int n = m * m, success = 1;
+  uint32_t key[2] = {key_in[0], key_in[1]};
+  memset(grid, 0, sizeof(int32_t) * (size_t)n);
+  for (int w = 0; w < N; ++w) {
+    uint32_t ks[4], ps[4];
+    oracle_split(key, 2, ks);        /* key, subkey = split(key): the new key is dropped ... */
+    oracle_split(&ks[2], 2, ps);     /* pick_start(subkey): key, subkey = split(key) */
+    key[0] = ps[0];                  /* ... the tuple carries pick_start's key from here on */
+    key[1] = ps[1];
+    uint8_t valid[ORACLE_MAX_CELLS];
+    int can_start = 0;
+    for (int c = 0; c < n; ++c) {
+      valid[c] = grid[c] == 0;
+      can_start |= valid[c];
+    }
+    first[w] = last[w] = -1;
+    if (!can_start) {
+      success = 0;
+      continue;
+    }
+    int cell = gumbel_top1(&ps[2], valid, n);
+    grid[cell] = 3 * w + POSITION;
+    first[w] = last[w] = cell;
+    int moved = 0;
+    for (int t = 0; t < max_length; ++t) { /* walk_randomly (:244-288) */
+      int32_t avail[64];
+      uint8_t ok[64];
+      int can_step = 0;
+      seq_available(grid, m, last[w], avail);
+      for (int k = 0; k < m + 1; ++k) {
+        ok[k] = avail[k] != -1;
+        can_step |= ok[k];
+      }
+      if (!can_step) break; /* the grid no longer changes: every later trip is a no-op too */
+      moved = 1;
+      uint32_t ss[4];
+      oracle_split(key, 2, ss); /* one_step: key, subkey = split(key) */
+      key[0] = ss[0];
+      key[1] = ss[1];
+      int pick = gumbel_top1(&ss[2], ok, m + 1);
+      int32_t nxt = avail[pick];
+      grid[nxt] = 3 * w + TARGET;
+      grid[last[w]] = 3 * w + PATH;
+      last[w] = nxt;
+    }
+    grid[first[w]] = 3 * w + POSITION; /* the first cell becomes the head again (:286) */
+    success = success && moved;
+  }
+  return success;
+}
+
+/* generate (:322-393) + generate_starts_ends (:395-431).  Returns the number of attempts
+ * (1 .. 2m), or 0 when every attempt failed (board all zero, starts = ends = (0, 0)). */
+int oracle_seq_rw_generate(const uint32_t key[2], int m, int N, int32_t *board /*[m][m]*/,
+                           int32_t *starts /*[N][2]*/, int32_t *ends /*[N][2]*/) {
+  int32_t first[ORACLE_MAX_AGENTS], last[ORACLE_MAX_AGENTS];
+  int start_max = 2 * m;
+  for (int i = 1; i <= start_max; ++i) {
+    if (seq_add_agents(key, m, N, start_max - i, board, first, last)) {
+      for (int w = 0; w < N; ++w) {
+        starts[2 * w] = first[w] / m;
+        starts[2 * w + 1] = first[w] % m;
+        ends[2 * w] = last[w] / m;
+        ends[2 * w + 1] = last[w] % m;
+      }
+      return i;
+    }
+  }
+  memset(board, 0, sizeof(int32_t) * (size_t)(m * m));
+  memset(starts, 0, sizeof(int32_t) * 2 * (size_t)N);
+  memset(ends, 0, sizeof(int32_t) * 2 * (size_t)N);
+  return 0;
+}
+
+/* SequentialRandomWalkGenerator.__call__
+ * (rl_training/online_generators/sequential_random_walk_generator.py:34-66), batched.
+ * On total failure all indices are (0, 0); the reference's scatter with duplicate indices is
+ * unspecified there -- this project applies the updates in agent order (last agent's target). */
+int oracle_seq_rw_generator_batch(const uint32_t *keys, int B, int m, int N, int32_t *grid,
+                                  int32_t *step_count, int32_t *start, int32_t *target,
+                                  int32_t *position, uint32_t *key_out, int32_t *solved,
+                                  int32_t *attempts, int threads) {
+  if (N > ORACLE_MAX_AGENTS || m * m > ORACLE_MAX_CELLS || m + 1 > 64) return -1;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+  for (int b = 0; b < B; ++b) {
+    state_view_t st = state_at(b, m, N, grid, step_count, start, target, position, key_out);
+    uint32_t ks[4];
+    int32_t scratch[m * m];
+    int32_t *board = solved ? solved + (size_t)b * m * m : scratch;
+    oracle_split(keys + 2 * b, 2, ks);
+    int tries = oracle_seq_rw_generate(&ks[0], m, N, board, st.start, st.target);
+    memset(st.grid, 0, sizeof(int32_t) * (size_t)(m * m));
+    for (int i = 0; i < N; ++i) st.grid[st.start[2 * i] * m + st.start[2 * i + 1]] = get_position(i);
+    for (int i = 0; i < N; ++i) st.grid[st.target[2 * i] * m + st.target[2 * i + 1]] = get_target(i);
+    memcpy(st.position, st.start, sizeof(int32_t) * 2 * (size_t)N);
+    *st.step_count = 0;
+    st.key[0] = ks[0];
+    st.key[1] = ks[1];
+    if (attempts) attempts[b] = tries;
+  }
+  return 0;
+}

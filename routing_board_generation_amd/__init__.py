@@ -10,8 +10,9 @@ from .connector import (Connector, DenseRewardFn, MultiToSingleWrapper,  # noqa:
                         VmapAutoResetWrapper)
 from .interface.board_generator_interface import BoardGenerator, BoardName  # noqa: F401
 from .offline_generation import BoardDatasetGenerator  # noqa: F401
+from .board_generation.sequential_random_walk import SequentialRandomWalkBoard  # noqa: F401
 from .online_generators import (Generator, ParallelRandomWalkGenerator,  # noqa: F401
-                                UniformRandomGenerator)
+                                SequentialRandomWalkGenerator, UniformRandomGenerator)
 from .random import PRNGKey, split  # noqa: F401
 from .types import Agent, Observation, State, StepType, TimeStep  # noqa: F401
 

@@ -22,6 +22,7 @@
 #include "rbg_device.h"
 #include "rbg_walk.h"
 #include "rbg_env.h"
+#include "rbg_seqwalk.h"
 
 namespace {
 
@@ -94,6 +95,48 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
     if (a.key_out) *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(key.a, key.b);
     if (a.step_count) a.step_count[b] = 0;
     if (a.iters) a.iters[b] = w.iters;
+  }
+}
+
+// SequentialRandomWalkBoard.generate / SequentialRandomWalkGenerator.__call__ (one board per wave)
+__global__ __launch_bounds__(kBlock) void seq_rw_generate_kernel(GenArgs a) {
+  const int lane = threadIdx.x & (kWaveSize - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * kWavesPerBlock + wib;
+  if (b >= a.B) return;
+  const SubWave<64> sw(lane);
+  const Geo g = a.g;
+  uint32_t *board = g_lds + wib * slab_words<64>(g);
+  Key2 key;
+  key.a = a.keys[2 * (size_t)b];
+  key.b = a.keys[2 * (size_t)b + 1];
+  if (a.split_first) {  // key, pos_key = split(key)  (sequential_random_walk_generator.py:40)
+    Key2 unused;
+    split2_lanes(sw, key, key, unused);
+  }
+  int first_cell, last_cell;
+  const int attempts = seq_rw_generate(board, g, a.N, key, lane, first_cell, last_cell);
+  const size_t gofs = (size_t)b * g.n;
+  if (a.solved_grid) store_grid<64, false>(board, g, lane, a.solved_grid + gofs);
+  if (attempts == 0 && lane == 0) {
+    // total failure: every start/end is (0, 0); the scatter order of duplicate indices is
+    // unspecified in the reference -- here updates apply in agent order (last agent's target)
+    board[pad_index(g, 0, 0)] = 3u * (uint32_t)a.N;
+  }
+  wave_lds_fence();
+  if (a.train_grid) store_grid<64, true>(board, g, lane, a.train_grid + gofs);
+  if (lane < a.N) {
+    const int r0 = div_m(g, first_cell), r1 = div_m(g, last_cell);
+    const int2 s2 = make_int2(r0, first_cell - r0 * g.m), t2 = make_int2(r1, last_cell - r1 * g.m);
+    const size_t o = ((size_t)b * a.N + lane) * 2;
+    *reinterpret_cast<int2 *>(&a.start[o]) = s2;
+    *reinterpret_cast<int2 *>(&a.target[o]) = t2;
+    if (a.position) *reinterpret_cast<int2 *>(&a.position[o]) = s2;
+  }
+  if (lane == 0) {
+    if (a.key_out) *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(key.a, key.b);
+    if (a.step_count) a.step_count[b] = 0;
+    if (a.iters) a.iters[b] = attempts;
   }
 }
 
@@ -506,6 +549,25 @@ int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
     hipLaunchKernelGGL(prw_generate_kernel<64>, grid, block, lds, st, a);
   }
   return check_hip(hipGetLastError(), "rbg_prw_generate");
+}
+
+int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
+                        int32_t *solved_grid, int32_t *train_grid, int32_t *start,
+                        int32_t *target, int32_t *position, int32_t *step_count,
+                        uint32_t *key_out, int32_t *attempts, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_seq_rw_generate: B < 0");
+  if (m < 3) return fail(RBG_E_SHAPE, "rbg_seq_rw_generate: m must be >= 3");
+  GenArgs a;
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (B == 0) return 0;
+  if (!keys || !start || !target) return fail(RBG_E_NULL, "rbg_seq_rw_generate: NULL pointer");
+  if (int rc = check_align(a.g, solved_grid, train_grid, nullptr)) return rc;
+  a.keys = keys; a.B = B; a.N = N; a.split_first = split_first != 0;
+  a.solved_grid = solved_grid; a.train_grid = train_grid; a.start = start; a.target = target;
+  a.position = position; a.step_count = step_count; a.key_out = key_out; a.iters = attempts;
+  hipLaunchKernelGGL(seq_rw_generate_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
+                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  return check_hip(hipGetLastError(), "rbg_seq_rw_generate");
 }
 
 int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *train_grid,

@@ -54,6 +54,10 @@ def make_online_generator(generation_type: str, grid_size: int, num_agents: int,
                                      board_name=generation_type, **kwargs)
     if generation_type == "online_parallel_rw":
         return ParallelRandomWalkGenerator(grid_size=grid_size, num_agents=num_agents)
+    if generation_type == "online_seq_rw":
+        from ..online_generators import SequentialRandomWalkGenerator
+
+        return SequentialRandomWalkGenerator(grid_size=grid_size, num_agents=num_agents)
     if generation_type == "online_uniform":
         return UniformRandomGenerator(grid_size=grid_size, num_agents=num_agents)
     raise NotImplementedError(f"generation_type {generation_type!r} is outside the hot path")

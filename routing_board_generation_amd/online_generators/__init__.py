@@ -1,2 +1,3 @@
 from .uniform_generator import Generator, UniformRandomGenerator  # noqa: F401
 from .parallel_random_walk_generator import ParallelRandomWalkGenerator  # noqa: F401
+from .sequential_random_walk_generator import SequentialRandomWalkGenerator  # noqa: F401

@@ -160,6 +160,29 @@ def prw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool, want_sol
     return o
 
 
+def seq_rw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool,
+                    want_solved: bool = True, want_train: bool = True):
+    """SequentialRandomWalk: dict(solved_grid?, train_grid?, start, target, position, step_count,
+    key_out, attempts)."""
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    o = {"start": torch.empty((B, N, 2), **i32), "target": torch.empty((B, N, 2), **i32),
+         "position": torch.empty((B, N, 2), **i32), "step_count": torch.empty((B,), **i32),
+         "key_out": torch.empty((B, 2), dtype=torch.uint32, device=dev),
+         "attempts": torch.empty((B,), **i32)}
+    if want_solved:
+        o["solved_grid"] = torch.empty((B, m, m), **i32)
+    if want_train:
+        o["train_grid"] = torch.empty((B, m, m), **i32)
+    nat.check(nat.lib().rbg_seq_rw_generate(
+        keys.data_ptr(), B, m, N, int(split_first), _ptr(o.get("solved_grid")),
+        _ptr(o.get("train_grid")), o["start"].data_ptr(), o["target"].data_ptr(),
+        o["position"].data_ptr(), o["step_count"].data_ptr(), o["key_out"].data_ptr(),
+        o["attempts"].data_ptr(), _stream(dev)), "rbg_seq_rw_generate")
+    return o
+
+
 def uniform_generate(keys: torch.Tensor, m: int, N: int) -> StateBufs:
     keys = check_keys(keys)
     B, dev = keys.shape[0], keys.device

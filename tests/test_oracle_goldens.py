@@ -237,3 +237,29 @@ def test_validity_invariants_c1_and_c2_shapes(oracle):
             check_solved_board(solved[b], st["start"][b], st["target"][b])
             # training grid holds heads+targets only
             assert (st["grid"][b] != 0).sum() == 2 * N - (st["start"][b] == st["target"][b]).all(1).sum()
+
+
+# --------------------------------------------------------------------------- SequentialRandomWalk
+def test_sequential_random_walk_generator_golden(oracle, goldens):  # profiling nb cell 7 (G7)
+    s = goldens["notebook"]["single_10x10_5_PRNGKey0"]["sequential_random_walk"]
+    st, solved, attempts = oracle.seq_rw_generator_batch(oracle.prng_key(0)[None], 10, 5)
+    assert (st["grid"][0] == np.asarray(s["grid"])).all()
+    assert (st["start"][0] == np.asarray(s["start"])).all()
+    assert (st["target"][0] == np.asarray(s["target"])).all()
+    assert (st["position"][0] == np.asarray(s["position"])).all()
+    assert (st["key"][0] == np.asarray(s["key"], np.uint32)).all()
+    assert attempts[0] == 1
+    check_solved_board(solved[0], st["start"][0], st["target"][0])
+
+
+def test_sequential_random_walk_retries_and_failure(oracle):
+    """Dense boards: a wire that cannot start or move fails the attempt; the board is retried with
+    max_length - 1 and the SAME key; after 2m failures the board is all zero."""
+    st, solved, attempts = oracle.seq_rw_generator_batch(oracle.split(oracle.prng_key(1), 128), 4, 7,
+                                                         threads=2)
+    assert (attempts == 0).any() and (attempts > 1).any()
+    failed = attempts == 0
+    assert (solved[failed] == 0).all() and (st["start"][failed] == 0).all()
+    assert (st["grid"][failed][:, 0, 0] == 21).all()
+    for b in np.flatnonzero(~failed)[:20]:
+        check_solved_board(solved[b], st["start"][b], st["target"][b])
