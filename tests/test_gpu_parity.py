@@ -488,3 +488,21 @@ def test_launches_follow_the_current_stream_and_capture_into_a_graph(rbg, torch_
     torch_mod.cuda.synchronize()
     for k in ("grid", "step_count", "position", "target"):
         assert torch_mod.equal(st[k], expect[k]), k
+
+
+def test_large_batch_indexing(rbg, oracle):
+    """65536 boards in one launch (8192 workgroups): spot-check 3 x 512 boards against the oracle
+    and the whole batch for determinism of the per-board result (independent of batch position)."""
+    from routing_board_generation_amd import ops
+
+    B, m, N = 65536, 16, 10
+    keys = _keys(rbg, 77, B)
+    out = ops.prw_generate(keys, m, N, split_first=True, want_iters=True)
+    solved = to_np(out["solved_grid"])
+    for lo in (0, 30000, B - 512):
+        st, esolved, eit = oracle.generate_batch(to_np(keys[lo:lo + 512]), m, N, threads=8)
+        assert (solved[lo:lo + 512] == esolved).all()
+        assert (to_np(out["target"])[lo:lo + 512] == st["target"]).all()
+        assert (to_np(out["iters"])[lo:lo + 512] == eit).all()
+    tail = ops.prw_generate(keys[B - 1000:].contiguous(), m, N, split_first=True)
+    assert (to_np(tail["solved_grid"]) == solved[B - 1000:]).all()
