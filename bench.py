@@ -107,6 +107,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--env-steps", type=int, default=100,
                     help="env steps of the secondary Connector rollout measurement (0 = skip)")
+    ap.add_argument("--stream-batch", type=int, default=65536,
+                    help="batch of the pure-step HBM streaming check (0 = skip)")
     ap.add_argument("--rollout-steps", type=int, default=50,
                     help="env steps per launch of the fused random-policy rollout (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
@@ -221,6 +223,33 @@ def main() -> None:
                                  "kernel_avg_ms": k_avg,
                                  "note": "duration of one env step = random_actions_kernel + "
                                          "connector_kernel (fused auto-reset walks included)"}}
+
+        # the same kernel as a pure stream (no env terminates, batch large enough to leave the
+        # Infinity Cache): how close connector_kernel gets to the HBM roofline when neither resets
+        # nor the host's launch rate limit it
+        if rank == 0 and args.stream_batch > 0:
+            Bs = args.stream_batch
+            skeys = rbg.split(rbg.PRNGKey(1, device=dev), Bs)
+            sst, sts = ops.connector_reset(skeys, m, N)
+            sso = ops.alloc_state(Bs, m, N, dev)
+            noop = torch.zeros((Bs, N), dtype=torch.int32, device=dev)
+            for _ in range(3):
+                ops.connector_step(sst, noop, time_limit=1 << 30, state_out=sso, timestep=sts)
+            pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            pe0.record()
+            for _ in range(20):
+                ops.connector_step(sst, noop, time_limit=1 << 30, state_out=sso, timestep=sts)
+            pe1.record()
+            torch.cuda.synchronize(dev)
+            p_ms = pe0.elapsed_time(pe1) / 20
+            p_ach = Bs * sb / (p_ms * 1e-3) / 1e9
+            env_step["pure_step_stream"] = {
+                "batch": Bs, "kernel_avg_ms": p_ms, "achieved": p_ach, "unit": "GB/s",
+                "peak": HBM_PEAK_GBS, "frac": p_ach / HBM_PEAK_GBS,
+                "note": "connector_kernel, NOOP actions (no terminations), working set "
+                        f"{Bs * sb / 1e6:.0f} MB > 256 MiB Infinity Cache"}
+            del sst, sts, sso, noop
 
     # ---------------------------------------------------------------- secondary: fused rollout
     rollout = None

@@ -76,7 +76,10 @@ __device__ __forceinline__ void store_obs(const uint32_t *board, const Geo &g, i
         o.y = obs_value(v.y, 3 * i, n3);
         o.z = obs_value(v.z, 3 * i, n3);
         o.w = obs_value(v.w, 3 * i, n3);
-        *reinterpret_cast<int4 *>(&obs[(size_t)i * g.n + idx]) = o;
+        // write-once stream: non-temporal keeps it from evicting the states in L2/Infinity Cache
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i ov = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(ov, reinterpret_cast<v4i *>(&obs[(size_t)i * g.n + idx]));
       }
     }
   } else {
