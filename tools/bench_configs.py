@@ -39,7 +39,9 @@ def cpu_rate(fn, units):
 def main():
     from oracle import oracle as O
 
-    threads = min(len(os.sched_getaffinity(0)), 64)
+    from bench import host_cpu_share
+
+    threads = host_cpu_share()
     rows = []
 
     def gen_row(name, m, N, B, kind="prw"):
