@@ -467,7 +467,7 @@ int check_align(const Geo &g, const void *p0, const void *p1, const void *p2) {
 
 // dynamic LDS of one 256-thread workgroup: 4 waves x (64 / lpb) boards x (board + scratch)
 size_t lds_bytes(const Geo &g, int lpb = kWaveSize) {
-  const size_t slab = (size_t)((g.words + 3) & ~3) + (size_t)(2 * lpb + 4);
+  const size_t slab = (size_t)((g.words + 3) & ~3) + (size_t)(4 * lpb);
   return (size_t)kWavesPerBlock * (size_t)(kWaveSize / lpb) * slab * sizeof(uint32_t);
 }
 

@@ -221,10 +221,12 @@ __device__ __forceinline__ void unpad_index(const Geo &g, int P, int &r, int &c)
 __device__ __forceinline__ int board_words(const Geo &g) { return (g.words + 3) & ~3; }
 
 // Per-board scratch next to the board: Threefry pipeline words (2N <= 2*LPB) or the candidate
-// list of shuffle_prefix (2*LPB words), plus a 4-word dump slot for branch-free stores.
+// list of shuffle_prefix (2*LPB words), followed by 2*LPB dump words: lanes that have nothing to
+// store park their branch-free stores there, each lane in its OWN two words (same-address LDS
+// stores and atomics from many lanes serialise).
 template <int LPB>
 __device__ __host__ constexpr int scratch_words() {
-  return 2 * LPB + 4;
+  return 4 * LPB;
 }
 template <int LPB>
 __device__ __forceinline__ int slab_words(const Geo &g) {  // one board + its scratch

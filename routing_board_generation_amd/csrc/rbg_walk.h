@@ -112,7 +112,7 @@ struct PrngLanes {  // per-lane constants of the single-evaluation layout (2N + 
 template <int LPB>
 __device__ __forceinline__ PrngLanes<LPB> prng_lanes(int N, int l) {
   PrngLanes<LPB> p;
-  const int twoN = 2 * N, s = l, dump = 2 * LPB;
+  const int twoN = 2 * N, s = l, dump = 2 * LPB + 2 * l;  // this lane's own dump words
   p.r_uni = s < N;
   p.r_split = !p.r_uni && s < twoN;
   p.w_read = p.r_uni ? 2 * s : 0;
@@ -171,7 +171,7 @@ __device__ __forceinline__ float prng_round_single(const SubWave<LPB> &sw, uint3
 
 // One whole round when 2N + 2 > 64 (full-wave boards with N >= 32): two or three evaluations.
 __device__ __forceinline__ float prng_round_multi(uint32_t *W, int N, int lane, Key2 &kcur) {
-  const int twoN = 2 * N, dump = 2 * kWaveSize;
+  const int twoN = 2 * N, dump = 2 * kWaveSize + 2 * lane;
   float u = 0.0f;
   uint32_t nk0 = 0u, nk1 = 0u;
 #pragma unroll 1
@@ -266,6 +266,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
   }
 
   const int S = g.S;
+  const int idle_word = l % (2 * S);  // the first two padded rows are walls
   // Every iteration that runs moves at least the highest-id mover of a live board into an empty
   // cell, so a board is finished after at most n - N trips; the explicit bound keeps a faulty
   // board from spinning.
@@ -332,8 +333,10 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     const bool mover = c4 > 0;  // a blocked agent's -1 sentinel maps to NOOP / invalid UP (A.5)
     // step = signed byte `dir` of [-S, +S, -1, +1]: one shift + one v_bfe_i32
     const int dP = __builtin_amdgcn_sbfe((int)g.step_table, (uint32_t)dir * 8u, 8u);
-    // non-movers aim at word 0, a wall: max(wall, wire) leaves it unchanged (branch-free)
-    const int Q = mover ? P + dP : 0;
+    // branch-free: a non-moving agent "claims" its own head cell (already = wire), the other lanes
+    // one wall word each (max(wall, wire) = wall) -- distinct addresses, because same-address LDS
+    // atomics from many lanes serialise
+    const int Q = mover ? P + dP : is_agent ? P : idle_word;
 
     // ---- _step_agents (:101-145): contested cell -> highest id wins, losers stay ----------
     atomicMax(&board[Q], wire);
@@ -343,7 +346,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     // the remaining Threefry rounds hide the ds_max + read-back round trip
     if (kSingle) u_next = prng_second<LPB>(sw, W, pl, tf, kcur);
     __builtin_amdgcn_sched_barrier(0);
-    const bool won = after == wire;  // never true for the wall
+    const bool won = after == wire;  // never true for a wall; a no-op for a non-moving agent
     w.P = won ? Q : P;
     wave_lds_fence();
     u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
