@@ -119,9 +119,11 @@ int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_fir
                         uint32_t *key_out, int32_t *attempts, void *stream);
 
 /* vmap(UniformRandomGenerator(m, N).__call__)(keys)
- *   routing_board_generation/rl_training/online_generators/uniform_generator.py:70-109 */
+ *   routing_board_generation/rl_training/online_generators/uniform_generator.py:70-109
+ * train_grid, position (= start), step_count (= 0) and key_out are nullable. */
 int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *train_grid,
-                         int32_t *start, int32_t *target, uint32_t *key_out, void *stream);
+                         int32_t *start, int32_t *target, int32_t *position,
+                         int32_t *step_count, uint32_t *key_out, void *stream);
 
 /* vmap(BoardDatasetGeneratorJAX.__call__)(keys): sample one of `n_boards` pre-generated boards
  *   routing_board_generation/rl_training/offline_generation/dataset_generator_jax.py:112-141

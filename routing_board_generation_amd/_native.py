@@ -60,7 +60,8 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "rbg_uniform_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     "rbg_dataset_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.POINTER(State), C.c_void_p, C.c_void_p]),
     "rbg_connector_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(State),

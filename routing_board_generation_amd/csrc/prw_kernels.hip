@@ -147,6 +147,8 @@ struct UniformArgs {
   int32_t *train_grid;
   int32_t *start;
   int32_t *target;
+  int32_t *position;
+  int32_t *step_count;
   uint32_t *key_out;
 };
 
@@ -181,11 +183,14 @@ __global__ __launch_bounds__(kBlock) void uniform_generate_kernel(UniformArgs a)
     const size_t o = ((size_t)b * a.N + lane) * 2;
     *reinterpret_cast<int2 *>(&a.start[o]) = make_int2(r0, c0);
     *reinterpret_cast<int2 *>(&a.target[o]) = make_int2(tr, tc);
+    if (a.position) *reinterpret_cast<int2 *>(&a.position[o]) = make_int2(r0, c0);
   }
   wave_lds_fence();
   if (a.train_grid) store_grid<64, false>(board, g, lane, a.train_grid + (size_t)b * g.n);
-  if (lane == 0 && a.key_out)
-    *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(kept.a, kept.b);
+  if (lane == 0) {
+    if (a.key_out) *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(kept.a, kept.b);
+    if (a.step_count) a.step_count[b] = 0;
+  }
 }
 
 struct EnvArgs {
@@ -571,7 +576,8 @@ int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_fir
 }
 
 int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *train_grid,
-                         int32_t *start, int32_t *target, uint32_t *key_out, void *stream) {
+                         int32_t *start, int32_t *target, int32_t *position,
+                         int32_t *step_count, uint32_t *key_out, void *stream) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_uniform_generate: B < 0");
   UniformArgs a;
   if (int rc = make_geo(m, N, &a.g, 2 * N)) return rc;
@@ -580,7 +586,8 @@ int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *tra
   if (!keys || !start || !target) return fail(RBG_E_NULL, "rbg_uniform_generate: NULL pointer");
   if (int rc = check_align(a.g, train_grid, nullptr, nullptr)) return rc;
   a.keys = keys; a.B = B; a.N = N;
-  a.train_grid = train_grid; a.start = start; a.target = target; a.key_out = key_out;
+  a.train_grid = train_grid; a.start = start; a.target = target; a.position = position;
+  a.step_count = step_count; a.key_out = key_out;
   hipLaunchKernelGGL(uniform_generate_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
                      dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
   return check_hip(hipGetLastError(), "rbg_uniform_generate");

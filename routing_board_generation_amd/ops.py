@@ -189,9 +189,8 @@ def uniform_generate(keys: torch.Tensor, m: int, N: int) -> StateBufs:
     st = alloc_state(B, m, N, dev)
     nat.check(nat.lib().rbg_uniform_generate(
         keys.data_ptr(), B, m, N, st["grid"].data_ptr(), st["start"].data_ptr(),
-        st["target"].data_ptr(), st["key"].data_ptr(), _stream(dev)), "rbg_uniform_generate")
-    st["position"] = st["start"].clone()
-    st["step_count"].zero_()
+        st["target"].data_ptr(), st["position"].data_ptr(), st["step_count"].data_ptr(),
+        st["key"].data_ptr(), _stream(dev)), "rbg_uniform_generate")
     return st
 
 

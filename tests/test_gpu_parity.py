@@ -506,3 +506,27 @@ def test_large_batch_indexing(rbg, oracle):
         assert (to_np(out["iters"])[lo:lo + 512] == eit).all()
     tail = ops.prw_generate(keys[B - 1000:].contiguous(), m, N, split_first=True)
     assert (to_np(tail["solved_grid"]) == solved[B - 1000:]).all()
+
+
+# ------------------------------------------------------------------------------ C-ABI without Python
+def test_c_api_demo_program(oracle, tmp_path):
+    """examples/c_api_demo.cpp drives the library from plain C++ (no torch): same boards."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_api_demo")
+    libdir = os.path.join(root, "routing_board_generation_amd", "lib")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-w", "-I",
+                           os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_api_demo.cpp"), "-L", libdir,
+                           "-lrbg_prw", f"-Wl,-rpath,{libdir}", "-o", exe])
+    out = subprocess.check_output([exe, "1000"], text=True)
+    keys = oracle.split(oracle.prng_key(0), 1000)
+    _, solved, iters = oracle.generate_batch(keys, 16, 10, threads=8)
+    fnv = 1469598103934665603
+    for v in solved.astype(np.uint32).ravel().tolist():
+        fnv = ((fnv ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert f"walk_iters_sum {int(iters.sum())} " in out, out
+    assert f"solved_fnv1a {fnv:016x}" in out, out
+    assert "rollout 50 steps: episodes" in out

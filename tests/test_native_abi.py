@@ -53,7 +53,7 @@ def test_argument_errors_do_not_need_a_gpu(native):
     assert lib.rbg_prw_generate(one, 1, 16, 65, 1, None, None, one, one, None, None, None, None, None) == -2
     assert lib.rbg_prw_generate(one, 1, 3, 10, 1, None, None, one, one, None, None, None, None, None) == -2
     assert lib.rbg_prw_generate(one, -1, 16, 10, 1, None, None, one, one, None, None, None, None, None) == -2
-    assert lib.rbg_uniform_generate(one, 1, 4, 9, None, one, one, None, None) == -2
+    assert lib.rbg_uniform_generate(one, 1, 4, 9, None, one, one, None, None, None, None) == -2
     assert lib.rbg_split(0, 0, 4, None, None) == -1
     with pytest.raises(native.NativeLibraryError):
         native.check(-2, "rbg_prw_generate")
