@@ -107,6 +107,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--env-steps", type=int, default=100,
                     help="env steps of the secondary Connector rollout measurement (0 = skip)")
+    ap.add_argument("--rehearse-single-gpu", action="store_true",
+                    help="developer option: run all ranks on GPU 0 over gloo to rehearse the "
+                         "multi-rank path on a one-GPU box (numbers are meaningless)")
     ap.add_argument("--stream-batch", type=int, default=65536,
                     help="batch of the pure-step HBM streaming check (0 = skip)")
     ap.add_argument("--rollout-steps", type=int, default=50,
@@ -122,7 +125,9 @@ def main() -> None:
     import routing_board_generation_amd as rbg
     from routing_board_generation_amd import ops, sharding
 
-    rank, local_rank, world = sharding.init_distributed()
+    rank, local_rank, world = sharding.init_distributed(
+        backend="gloo" if args.rehearse_single_gpu else None,
+        single_device=args.rehearse_single_gpu)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with "
                          "torch.distributed.run --nproc-per-node N")
@@ -137,6 +142,9 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    if world > 1:  # the first collective pays communicator setup: keep it out of the timed region
+        sharding.all_reduce_metrics({"boards": 0.0}, device=dev)
 
     # ---------------------------------------------------------------- inputs resident in HBM
     all_keys = rbg.split(rbg.PRNGKey(0, device=dev), BATCH_PER_GPU * world)
