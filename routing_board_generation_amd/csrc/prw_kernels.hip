@@ -1,13 +1,18 @@
 // prw_kernels.hip -- hand-written gfx950 (CDNA4) kernels + the C-ABI of include/rbg_prw.h.
 //
-// One 64-lane wavefront owns one board / one env for the whole launch:
-//   * the board lives in LDS as a zero-copy "padded" image (2 wall rows above/below, 4 wall
-//     columns shared between consecutive rows) so that the 4-neighbour and neighbour-of-neighbour
-//     stencils need no bounds checks;
-//   * lane i < N is agent i (availability stencil, weighted choice, move);
+// Device code lives in the headers next to this file:
+//   rbg_device.h   jax's Threefry-2x32, sub-wave helpers, the padded LDS board
+//   rbg_walk.h     ParallelRandomWalk (one board per sub-wave of 16/32/64 lanes)
+//   rbg_env.h      Connector reset / step / observation pieces (one env per wavefront)
+//   rbg_seqwalk.h  SequentialRandomWalk (one board per wavefront)
+// Common design:
+//   * a board lives in LDS as a "padded" image (2 wall rows above/below, 4 wall columns shared
+//     between consecutive rows) so that the 4-neighbour and neighbour-of-neighbour stencils need
+//     no bounds checks;
+//   * sub-lane i < N is agent i (availability stencil, weighted choice, move);
 //   * the reference's "N private grid copies -> max-join -> correction mask" collision rule
 //     (JAXI/parallel_random_walk.py:119-145) collapses to ONE `ds_max_u32` per mover on the
-//     contested cell: the highest head value (= highest agent id) wins, losers never left;
+//     contested cell: the highest value (= highest agent id) wins, losers never left;
 //   * termination is a wave ballot; no __syncthreads anywhere (waves never talk to each other);
 //   * the PRNG is jax's Threefry-2x32 with jax's counter layout, in registers.
 // HBM traffic is the algorithmic minimum: keys in, dense int32 grids / agents out, coalesced.
