@@ -105,7 +105,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--env-steps", type=int, default=100,
+    ap.add_argument("--env-steps", type=int, default=300,
                     help="env steps of the secondary Connector rollout measurement (0 = skip)")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="developer option: run all ranks on GPU 0 over gloo to rehearse the "
@@ -195,43 +195,58 @@ def main() -> None:
                         "reported for the record; see DESIGN.md"}
 
     # ---------------------------------------------------------------- secondary: env.step rollout
+    # BASELINE configs[2] through the per-step API: every step = masked-uniform policy kernel +
+    # connector_kernel (state in/out + full observation through HBM), auto-reset on.  The loop
+    # reuses its buffers and prebuilt launch descriptors (ops.StepLoop).  Three variants:
+    #   prefetch     next-episode States generated ahead of time on a side stream (rbg_stash),
+    #                so a step launch never waits for a random walk           -> `value`
+    #   inline       the walk of every finished env runs inside the step launch
+    #   fused_policy prefetch + policy and step in one launch (rbg_connector_rollout, 1 step)
     env_step = None
     if args.env_steps > 0:
-        st, ts = ops.connector_reset(keys, m, N)
-        act = torch.empty((B, N), dtype=torch.int32, device=dev)
-
-        def env_iter(t):
-            ops.random_actions(keys, t, ts["action_mask"], out=act)
-            ops.connector_step(st, act, auto_reset=True, state_out=st, timestep=ts)
-
-        for t in range(10):
-            env_iter(t)
-        se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
-        t1 = time.perf_counter()
-        se0.record()
-        for t in range(args.env_steps):
-            env_iter(10 + t)
-        se1.record()
-        barrier()
-        env_elapsed = time.perf_counter() - t1
-        k_avg = se0.elapsed_time(se1) / args.env_steps  # policy + step kernels of one env step
-        em = sharding.all_reduce_metrics({"env_steps": float(B * args.env_steps),
-                                          "elapsed_s": env_elapsed}, device=dev)
         sb = env_step_bytes(m, N)
-        ach = B * sb / (k_avg * 1e-3) / 1e9
-        env_step = {"metric": "env_steps_per_sec", "value": em["env_steps"] / em["elapsed_s"],
-                    "unit": "env-steps/s", "steps": args.env_steps, "auto_reset": True,
-                    "policy": "rbg_random_actions (masked uniform)",
+
+        def run_loop(refill_every, fuse):
+            st = ops.alloc_state(B, m, N, dev)
+            ts = ops.alloc_timestep(B, m, N, dev)
+            loop = ops.StepLoop(st, ts, keys, refill_every=refill_every, fuse_policy=fuse)
+            loop.reset(keys)
+            for t in range(30):
+                loop.step(t)
+            se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            t1 = time.perf_counter()
+            se0.record()
+            for t in range(30, 30 + args.env_steps):
+                loop.step(t)
+            se1.record()
+            barrier()
+            el = time.perf_counter() - t1
+            loop.drain()
+            em = sharding.all_reduce_metrics({"env_steps": float(B * args.env_steps),
+                                              "elapsed_s": el}, device=dev)
+            return em["env_steps"] / em["elapsed_s"], se0.elapsed_time(se1) / args.env_steps
+
+        v_pref, k_pref = run_loop(6, False)
+        v_inl, k_inl = run_loop(0, False)
+        v_fus, k_fus = run_loop(6, True)
+        ach = B * sb / (k_pref * 1e-3) / 1e9
+        env_step = {"metric": "env_steps_per_sec", "value": v_pref, "unit": "env-steps/s",
+                    "steps": args.env_steps, "auto_reset": True,
+                    "policy": "rbg_random_actions (masked uniform), one launch per step",
+                    "variants": {"prefetch": v_pref, "inline_reset": v_inl,
+                                 "prefetch_fused_policy": v_fus},
+                    "ms_per_step": {"prefetch": k_pref, "inline_reset": k_inl,
+                                    "prefetch_fused_policy": k_fus},
                     "roofline": {"bound": "hbm", "kernel": "connector_kernel", "achieved": ach,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "traffic": measured_traffic("connector_kernel", B),
                                  "algorithmic_bytes_per_launch": B * sb,
-                                 "bytes_per_env_step": sb,
-                                 "kernel_avg_ms": k_avg,
-                                 "note": "duration of one env step = random_actions_kernel + "
-                                         "connector_kernel (fused auto-reset walks included)"}}
-
+                                 "bytes_per_env_step": sb, "kernel_avg_ms": k_pref,
+                                 "note": "duration of one env step of the prefetch variant = "
+                                         "random_actions_kernel + connector_kernel (event span "
+                                         "/ steps, launch gaps included); refills overlap on a "
+                                         "side stream"}}
         # the same kernel as a pure stream (no env terminates, batch large enough to leave the
         # Infinity Cache): how close connector_kernel gets to the HBM roofline when neither resets
         # nor the host's launch rate limit it

@@ -156,6 +156,42 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
                        const int32_t *action, const rbg_env_params *params,
                        const rbg_timestep *timestep, void *stream);
 
+/* ---- auto-reset without the walk on the step's critical path --------------------------------
+ * VmapAutoResetWrapper restarts a finished episode from split(state.key)[0], and state.key does
+ * not change during an episode: the next episode's State is known as soon as the current one
+ * starts.  A stash holds that State per env, produced by rbg_stash_refill on a SIDE stream while
+ * the main stream keeps stepping; the step then copies it instead of walking.
+ *   next        a full rbg_state for B envs: next[b] = reset(split(tag[b])[0])
+ *   tag         uint32 [B][2]: the State.key next[b] was generated for (zero-initialised)
+ *   ready_at    int32 [B]: first launch tick that may consume the entry (zero-initialised)
+ *   refill_key  uint32 [B][2]: State.key of the running episode, i.e. the entry wanted next
+ *   hits        int32 [B], nullable: resets served from the stash (diagnostics; caller zeroes)
+ * Protocol (host-driven, kernel boundaries only -- no in-kernel cross-stream flags):
+ *   every reset/step launch has a tick t = 0, 1, 2, ...; it is followed by rbg_stash_refill R_t
+ *   on the side stream (which waits for the launch).  A launch that (re)starts env b writes
+ *   refill_key[b] and ready_at[b] = t + ready_delay; launch t must wait (stream event) for
+ *   R_{t - ready_delay} before it starts.  An entry is consumed only if tick >= ready_at[b] and
+ *   tag[b] == state.key[b]; otherwise the walk runs inline, so results never depend on timing. */
+typedef struct rbg_stash {
+  rbg_state next;
+  uint32_t *tag;
+  int32_t *ready_at;
+  uint32_t *refill_key;
+  int32_t *hits;
+} rbg_stash;
+
+/* rbg_connector_reset / rbg_connector_step with a stash (NULL stash = the plain calls). */
+int rbg_connector_reset_prefetch(const uint32_t *keys, int B, int m, int N, const rbg_state *state,
+                                 const rbg_timestep *timestep, const rbg_stash *stash, int tick,
+                                 int ready_delay, void *stream);
+int rbg_connector_step_prefetch(int B, int m, int N, const rbg_state *state_in,
+                                const rbg_state *state_out, const int32_t *action,
+                                const rbg_env_params *params, const rbg_timestep *timestep,
+                                const rbg_stash *stash, int tick, int ready_delay, void *stream);
+/* Generate next[b] for every env with tag[b] != refill_key[b] (one wave per env; the others
+ * exit at once). */
+int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream);
+
 /* Masked-uniform random policy over the legal set (defined by this project; stands in for
  * [3P] jumanji.training.agents.random.RandomAgent in the rollout benchmark, BASELINE config 3):
  * at global step t, agent i of env b picks legal action number
@@ -189,6 +225,17 @@ int rbg_connector_rollout(int B, int m, int N, const rbg_state *state_in,
                           int n_steps, const rbg_env_params *params,
                           const rbg_rollout_stats *stats, const rbg_timestep *last_timestep,
                           void *stream);
+
+/* rbg_connector_rollout with a stash: the FIRST reset of an env inside the launch may take its
+ * State from the stash, later ones walk inline (with n_steps = 1 and last_timestep set this is a
+ * fused "random policy + step" launch, one kernel per env step). */
+int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_in,
+                                   const rbg_state *state_out, const uint32_t *policy_keys,
+                                   uint32_t t0, int n_steps, const rbg_env_params *params,
+                                   const rbg_rollout_stats *stats,
+                                   const rbg_timestep *last_timestep, const rbg_stash *stash,
+                                   int tick, int ready_delay, void *stream);
+
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,11 @@ class RolloutStats(C.Structure):
                 ("final_path_length", C.c_void_p)]
 
 
+class Stash(C.Structure):
+    _fields_ = [("next", State), ("tag", C.c_void_p), ("ready_at", C.c_void_p),
+                ("refill_key", C.c_void_p), ("hits", C.c_void_p)]
+
+
 class EnvParams(C.Structure):
     _fields_ = [("time_limit", C.c_int32), ("timestep_reward", C.c_float),
                 ("connected_reward", C.c_float), ("auto_reset", C.c_int32)]
@@ -66,6 +71,14 @@ SIGNATURES = {
                                      C.c_void_p, C.POINTER(State), C.c_void_p, C.c_void_p]),
     "rbg_connector_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(State),
                                       C.POINTER(Timestep), C.c_void_p]),
+    "rbg_connector_reset_prefetch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(State), C.POINTER(Timestep),
+                                               C.POINTER(Stash), C.c_int, C.c_int, C.c_void_p]),
+    "rbg_connector_step_prefetch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
+                                              C.POINTER(State), C.c_void_p, C.POINTER(EnvParams),
+                                              C.POINTER(Timestep), C.POINTER(Stash), C.c_int,
+                                              C.c_int, C.c_void_p]),
+    "rbg_stash_refill": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Stash), C.c_void_p]),
     "rbg_connector_observe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
                                         C.POINTER(Timestep), C.c_void_p]),
     "rbg_connector_step": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
@@ -75,6 +88,11 @@ SIGNATURES = {
                                         C.POINTER(State), C.c_void_p, C.c_uint32, C.c_int,
                                         C.POINTER(EnvParams), C.POINTER(RolloutStats),
                                         C.POINTER(Timestep), C.c_void_p]),
+    "rbg_connector_rollout_prefetch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
+                                                 C.POINTER(State), C.c_void_p, C.c_uint32,
+                                                 C.c_int, C.POINTER(EnvParams),
+                                                 C.POINTER(RolloutStats), C.POINTER(Timestep),
+                                                 C.POINTER(Stash), C.c_int, C.c_int, C.c_void_p]),
     "rbg_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
 }

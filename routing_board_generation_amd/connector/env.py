@@ -74,6 +74,8 @@ class Connector:
         self.grid_size = self._generator.grid_size
         self._viewer = viewer
         self._auto_reset = False  # switched on by VmapAutoResetWrapper
+        self._prefetch_delay = 0  # > 0: VmapAutoResetWrapper(prefetch=True)
+        self._prefetcher = None
 
     @property
     def unwrapped(self) -> "Connector":
@@ -89,7 +91,19 @@ class Connector:
         keys = (key if batched else key[None]).contiguous()
         if isinstance(self._generator, ParallelRandomWalkGenerator):
             # fused: walk + State + observation in one launch
-            st, ts = ops.connector_reset(keys, self.grid_size, self.num_agents)
+            if self._prefetch_delay > 0 and batched:
+                pf = self._prefetcher
+                if pf is not None:
+                    pf.drain()
+                pf = self._prefetcher = ops.Prefetcher(keys.shape[0], self.grid_size,
+                                                       self.num_agents, keys.device,
+                                                       self._prefetch_delay)
+                tick = pf.before_launch()
+                st, ts = ops.connector_reset_prefetch(keys, self.grid_size, self.num_agents,
+                                                      pf.stash, tick, pf.delay)
+                pf.after_launch()
+            else:
+                st, ts = ops.connector_reset(keys, self.grid_size, self.num_agents)
         else:
             st = _state_bufs(self._generator(keys), True)
             ts = ops.connector_observe(st)
@@ -101,6 +115,17 @@ class Connector:
         st = _state_bufs(state, batched)
         act = (action if batched else action[None]).to(torch.int32).contiguous()
         fused_reset = self._auto_reset and isinstance(self._generator, ParallelRandomWalkGenerator)
+        pf = self._prefetcher
+        if (fused_reset and batched and pf is not None
+                and pf.stash["tag"].shape[0] == st["grid"].shape[0]):
+            # next-episode States come from the stash when it holds them (same results either way)
+            tick = pf.before_launch()
+            so, ts = ops.connector_step_prefetch(st, act, pf.stash, tick, pf.delay,
+                                                 self.time_limit,
+                                                 self._reward_fn.timestep_reward,
+                                                 self._reward_fn.connected_reward)
+            pf.after_launch()
+            return _make_state(so, batched), _make_timestep(ts, batched)
         so, ts = ops.connector_step(st, act, self.time_limit, self._reward_fn.timestep_reward,
                                     self._reward_fn.connected_reward, auto_reset=fused_reset)
         if self._auto_reset and not fused_reset:

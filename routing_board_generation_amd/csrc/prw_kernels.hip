@@ -198,6 +198,16 @@ __global__ __launch_bounds__(kBlock) void uniform_generate_kernel(UniformArgs a)
   }
 }
 
+// Pre-generated next-episode states (include/rbg_prw.h::rbg_stash).  `next` of env b is the
+// State the auto-reset of an episode with State.key == tag[b] must produce.
+struct StashPtrs {
+  StatePtrs next;
+  uint32_t *tag;         // [B][2]
+  int32_t *ready_at;     // [B] first launch tick that may consume the entry
+  uint32_t *refill_key;  // [B][2] State.key of the running episode = the entry wanted next
+  int32_t *hits;         // [B] nullable diagnostics: resets served from the stash
+};
+
 struct EnvArgs {
   const uint32_t *keys;  // reset only
   int B, N;
@@ -208,7 +218,18 @@ struct EnvArgs {
   rbg_env_params p;
   TimestepPtrs ts;
   int mode;  // 0 reset (generate), 1 observe existing state, 2 step
+  StashPtrs stash;  // all NULL when resets are always generated inline
+  int tick, ready_delay;
 };
+
+// after a (re)start: ask the side-stream refill for the entry of the new episode's key
+__device__ __forceinline__ void request_refill(const StashPtrs &st, int b, int lane, Key2 key,
+                                               int ready_at) {
+  if (st.refill_key && lane == 0) {
+    *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)b]) = make_uint2(key.a, key.b);
+    st.ready_at[b] = ready_at;
+  }
+}
 
 __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
@@ -227,6 +248,7 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     kin.b = a.keys[2 * (size_t)b + 1];
     const Key2 key = regenerate(board, W, g, N, lane, kin, ag);
     store_state(board, g, N, b, lane, ag, 0, key, a.out);
+    request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
     write_observation(board, g, N, b, lane, ag, 0, a.ts);
     write_extras(board, g, N, b, lane, ag, a.ts);
     write_restart(N, b, lane, a.ts);
@@ -253,13 +275,55 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   if (res.last && a.p.auto_reset) {
     // VmapAutoResetWrapper._auto_reset: key, _ = split(state.key); state, ts = reset(key);
     // only the observation of the terminal timestep is replaced.
-    Key2 rk, unused;
-    split2_lanes(SubWave<64>(lane), key, rk, unused);
-    key = regenerate(board, W, g, N, lane, rk, ag);
+    // With a stash the new episode's State was generated ahead of time on a side stream
+    // (stash_refill_kernel) and is only copied here; the entry is valid iff it was generated for
+    // exactly this episode's key and the refill that wrote it is known to have completed
+    // (ready_at: synchronised through stream events on the host, never through in-kernel flags).
+    bool hit = false;
+    if (a.stash.tag) {
+      const uint2 tag = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
+      hit = a.tick >= a.stash.ready_at[b] && tag.x == key.a && tag.y == key.b;
+    }
+    if (hit) {
+      load_state(board, g, N, b, lane, a.stash.next, ag, step_count, key);
+      if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
+    } else {
+      Key2 rk, unused;
+      split2_lanes(SubWave<64>(lane), key, rk, unused);
+      key = regenerate(board, W, g, N, lane, rk, ag);
+    }
     step_count = 0;
+    request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
   }
   store_state(board, g, N, b, lane, ag, step_count, key, a.out);
   write_observation(board, g, N, b, lane, ag, step_count, a.ts);
+}
+
+// Side-stream producer of the stash: for every env whose entry is not the one its running
+// episode will need (tag != refill_key), generate G(split(refill_key)[0]) and publish it.
+struct RefillArgs {
+  int B, N;
+  Geo g;
+  StashPtrs stash;
+};
+
+__global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
+  const int lane = threadIdx.x & (kWaveSize - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * kWavesPerBlock + wib;
+  if (b >= a.B) return;
+  const uint2 want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
+  const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
+  if (want.x == have.x && want.y == have.y) return;  // wave-uniform: nothing to do for this env
+  uint32_t *board = g_lds + wib * slab_words<64>(a.g);
+  uint32_t *W = board + board_words(a.g);
+  const Geo g = a.g;
+  AgentRegs ag = {0, 0, 0, 0, 0, 0};
+  Key2 key = {want.x, want.y}, rk, unused;
+  split2_lanes(SubWave<64>(lane), key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
+  const Key2 next_key = regenerate(board, W, g, a.N, lane, rk, ag);
+  store_state(board, g, a.N, b, lane, ag, 0, next_key, a.stash.next);
+  if (lane == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -286,6 +350,8 @@ struct RolloutArgs {
   rbg_env_params p;
   RolloutStatsPtrs stats;
   TimestepPtrs ts;  // timestep of the LAST step of the rollout (all members nullable)
+  StashPtrs stash;  // optional next-episode stash: serves the FIRST reset of an env per launch
+  int tick, ready_delay;
 };
 
 __global__ __launch_bounds__(kBlock) void connector_rollout_kernel(RolloutArgs a) {
@@ -306,6 +372,7 @@ __global__ __launch_bounds__(kBlock) void connector_rollout_kernel(RolloutArgs a
   pk.b = a.policy_keys[2 * (size_t)b + 1];
 
   int episodes = 0, conn_made = 0, pen_steps = 0, fin_conn = 0, fin_plen = 0;
+  bool used_stash = false;
   uint32_t bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
   for (int s = 0; s < a.n_steps; ++s) {
     const int act = random_policy_action(pk, a.t0 + (uint32_t)s, (uint32_t)lane, bits);
@@ -323,10 +390,22 @@ __global__ __launch_bounds__(kBlock) void connector_rollout_kernel(RolloutArgs a
       fin_conn += __popcll(__ballot(res.connected));
       if (a.stats.final_path_length) fin_plen += count_path_cells(board, g, lane);
       if (a.p.auto_reset) {
-        Key2 rk, unused;
-        split2_lanes(SubWave<64>(lane), key, rk, unused);
-        key = regenerate(board, W, g, N, lane, rk, ag);
+        bool hit = false;
+        if (a.stash.tag && !used_stash) {
+          const uint2 tag = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
+          hit = a.tick >= a.stash.ready_at[b] && tag.x == key.a && tag.y == key.b;
+        }
+        if (hit) {
+          load_state(board, g, N, b, lane, a.stash.next, ag, step_count, key);
+          used_stash = true;  // the entry is consumed; later resets of this launch walk inline
+          if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
+        } else {
+          Key2 rk, unused;
+          split2_lanes(SubWave<64>(lane), key, rk, unused);
+          key = regenerate(board, W, g, N, lane, rk, ag);
+        }
         step_count = 0;
+        request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
         bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
       }
     }
@@ -619,6 +698,76 @@ int rbg_connector_reset(const uint32_t *keys, int B, int m, int N, const rbg_sta
   return launch_env(a, stream, "rbg_connector_reset");
 }
 
+static int fill_stash(const rbg_stash *stash, StashPtrs *out, const char *who) {
+  if (!stash) return 0;
+  if (!state_complete(&stash->next) || !stash->tag || !stash->ready_at || !stash->refill_key) {
+    snprintf(g_err, sizeof(g_err), "%s: incomplete stash", who);
+    return RBG_E_NULL;
+  }
+  out->next = to_ptrs(&stash->next);
+  out->tag = stash->tag;
+  out->ready_at = stash->ready_at;
+  out->refill_key = stash->refill_key;
+  out->hits = stash->hits;
+  return 0;
+}
+
+int rbg_connector_reset_prefetch(const uint32_t *keys, int B, int m, int N, const rbg_state *state,
+                                 const rbg_timestep *timestep, const rbg_stash *stash, int tick,
+                                 int ready_delay, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_reset_prefetch: B < 0");
+  EnvArgs a;
+  memset(&a, 0, sizeof(a));
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (B == 0) return 0;
+  if (!keys || !timestep) return fail(RBG_E_NULL, "rbg_connector_reset_prefetch: NULL pointer");
+  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_connector_reset_prefetch: incomplete state");
+  if (int rc = check_align(a.g, state->grid, timestep->obs_grid, stash ? stash->next.grid : nullptr))
+    return rc;
+  if (int rc = fill_stash(stash, &a.stash, "rbg_connector_reset_prefetch")) return rc;
+  a.keys = keys; a.B = B; a.N = N; a.out = to_ptrs(state); a.in = a.out;
+  a.ts = to_ptrs(timestep); a.mode = 0; a.tick = tick; a.ready_delay = ready_delay;
+  return launch_env(a, stream, "rbg_connector_reset_prefetch");
+}
+
+int rbg_connector_step_prefetch(int B, int m, int N, const rbg_state *state_in,
+                                const rbg_state *state_out, const int32_t *action,
+                                const rbg_env_params *params, const rbg_timestep *timestep,
+                                const rbg_stash *stash, int tick, int ready_delay, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_step_prefetch: B < 0");
+  if (!params) return fail(RBG_E_NULL, "rbg_connector_step_prefetch: NULL params");
+  if (params->time_limit < 1) return fail(RBG_E_PARAM, "rbg_connector_step_prefetch: time_limit < 1");
+  EnvArgs a;
+  memset(&a, 0, sizeof(a));
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (B == 0) return 0;
+  if (!action || !timestep) return fail(RBG_E_NULL, "rbg_connector_step_prefetch: NULL pointer");
+  if (!state_complete(state_in) || !state_complete(state_out))
+    return fail(RBG_E_NULL, "rbg_connector_step_prefetch: incomplete state");
+  if (int rc = check_align(a.g, state_in->grid, state_out->grid, timestep->obs_grid)) return rc;
+  if (stash)
+    if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
+  if (int rc = fill_stash(stash, &a.stash, "rbg_connector_step_prefetch")) return rc;
+  a.B = B; a.N = N; a.in = to_ptrs(state_in); a.out = to_ptrs(state_out); a.action = action;
+  a.p = *params; a.ts = to_ptrs(timestep); a.mode = 2; a.tick = tick; a.ready_delay = ready_delay;
+  return launch_env(a, stream, "rbg_connector_step_prefetch");
+}
+
+int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_stash_refill: B < 0");
+  RefillArgs a;
+  memset(&a, 0, sizeof(a));
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (B == 0) return 0;
+  if (!stash) return fail(RBG_E_NULL, "rbg_stash_refill: NULL stash");
+  if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
+  if (int rc = fill_stash(stash, &a.stash, "rbg_stash_refill")) return rc;
+  a.B = B; a.N = N;
+  hipLaunchKernelGGL(stash_refill_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
+                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  return check_hip(hipGetLastError(), "rbg_stash_refill");
+}
+
 int rbg_connector_observe(int B, int m, int N, const rbg_state *state,
                           const rbg_timestep *timestep, void *stream) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_observe: B < 0");
@@ -657,6 +806,16 @@ int rbg_connector_rollout(int B, int m, int N, const rbg_state *state_in,
                           int n_steps, const rbg_env_params *params,
                           const rbg_rollout_stats *stats, const rbg_timestep *last_timestep,
                           void *stream) {
+  return rbg_connector_rollout_prefetch(B, m, N, state_in, state_out, policy_keys, t0, n_steps,
+                                        params, stats, last_timestep, nullptr, 0, 0, stream);
+}
+
+int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_in,
+                                   const rbg_state *state_out, const uint32_t *policy_keys,
+                                   uint32_t t0, int n_steps, const rbg_env_params *params,
+                                   const rbg_rollout_stats *stats,
+                                   const rbg_timestep *last_timestep, const rbg_stash *stash,
+                                   int tick, int ready_delay, void *stream) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_rollout: B < 0");
   if (n_steps < 1) return fail(RBG_E_PARAM, "rbg_connector_rollout: n_steps < 1");
   if (!params) return fail(RBG_E_NULL, "rbg_connector_rollout: NULL params");
@@ -680,6 +839,10 @@ int rbg_connector_rollout(int B, int m, int N, const rbg_state *state_in,
     a.stats = sp;
   }
   if (last_timestep) a.ts = to_ptrs(last_timestep);
+  if (stash)
+    if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
+  if (int rc = fill_stash(stash, &a.stash, "rbg_connector_rollout_prefetch")) return rc;
+  a.tick = tick; a.ready_delay = ready_delay;
   hipLaunchKernelGGL(connector_rollout_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
                      dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
   return check_hip(hipGetLastError(), "rbg_connector_rollout");

@@ -256,6 +256,232 @@ def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
     return so, ts
 
 
+# ------------------------------------------------------------------------------------- prefetch
+def alloc_stash(B: int, m: int, N: int, device) -> dict:
+    """Buffers of include/rbg_prw.h::rbg_stash (tag / ready_at / refill_key / hits zeroed)."""
+    return {"next": alloc_state(B, m, N, device),
+            "tag": torch.zeros((B, 2), dtype=torch.uint32, device=device),
+            "ready_at": torch.zeros((B,), dtype=torch.int32, device=device),
+            "refill_key": torch.zeros((B, 2), dtype=torch.uint32, device=device),
+            "hits": torch.zeros((B,), dtype=torch.int32, device=device)}
+
+
+def _stash_struct(stash: dict, B: int, m: int, N: int) -> nat.Stash:
+    nxt = _state_struct(stash["next"], B, m, N)
+    _check(stash["tag"], torch.uint32, (B, 2), "stash.tag")
+    _check(stash["ready_at"], torch.int32, (B,), "stash.ready_at")
+    _check(stash["refill_key"], torch.uint32, (B, 2), "stash.refill_key")
+    _check(stash["hits"], torch.int32, (B,), "stash.hits")
+    return nat.Stash(nxt, stash["tag"].data_ptr(), stash["ready_at"].data_ptr(),
+                     stash["refill_key"].data_ptr(), stash["hits"].data_ptr())
+
+
+def connector_reset_prefetch(keys: torch.Tensor, m: int, N: int, stash: dict, tick: int,
+                             ready_delay: int, state: Optional[StateBufs] = None,
+                             timestep: Optional[TimestepBufs] = None):
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    st = state if state is not None else alloc_state(B, m, N, dev)
+    ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
+    s, t, h = _state_struct(st, B, m, N), _timestep_struct(ts, B, m, N), _stash_struct(stash, B, m, N)
+    nat.check(nat.lib().rbg_connector_reset_prefetch(
+        keys.data_ptr(), B, m, N, C.byref(s), C.byref(t), C.byref(h), int(tick),
+        int(ready_delay), _stream(dev)), "rbg_connector_reset_prefetch")
+    return st, ts
+
+
+def connector_step_prefetch(state: StateBufs, action: torch.Tensor, stash: dict, tick: int,
+                            ready_delay: int, time_limit: int = 50,
+                            timestep_reward: float = -0.03, connected_reward: float = 0.1,
+                            state_out: Optional[StateBufs] = None,
+                            timestep: Optional[TimestepBufs] = None):
+    """Auto-resetting step that takes finished episodes' next State from `stash` when it can."""
+    B, m, _ = state["grid"].shape
+    N = state["start"].shape[1]
+    dev = state["grid"].device
+    _check(action, torch.int32, (B, N), "action")
+    so = state_out if state_out is not None else alloc_state(B, m, N, dev)
+    ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
+    si, s_o = _state_struct(state, B, m, N), _state_struct(so, B, m, N)
+    t, h = _timestep_struct(ts, B, m, N), _stash_struct(stash, B, m, N)
+    p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward), 1)
+    nat.check(nat.lib().rbg_connector_step_prefetch(
+        B, m, N, C.byref(si), C.byref(s_o), action.data_ptr(), C.byref(p), C.byref(t),
+        C.byref(h), int(tick), int(ready_delay), _stream(dev)), "rbg_connector_step_prefetch")
+    return so, ts
+
+
+def stash_refill(stash: dict, m: int) -> None:
+    """Launch the refill on torch's CURRENT stream (callers put it on a side stream)."""
+    B, N = stash["next"]["start"].shape[0], stash["next"]["start"].shape[1]
+    dev = stash["tag"].device
+    h = _stash_struct(stash, B, m, N)
+    nat.check(nat.lib().rbg_stash_refill(B, m, N, C.byref(h), _stream(dev)), "rbg_stash_refill")
+
+
+class Prefetcher:
+    """Host side of the stash protocol (include/rbg_prw.h::rbg_stash): numbers the reset/step
+    launches (ticks), runs rbg_stash_refill after each of them on a side stream, and makes launch
+    t wait for the refill of launch t - delay -- all through stream events."""
+
+    def __init__(self, B: int, m: int, N: int, device, delay: int = 4) -> None:
+        self.m, self.delay = m, max(1, int(delay))
+        self.stash = alloc_stash(B, m, N, device)
+        self.sides = [torch.cuda.Stream(device=device) for _ in range(min(self.delay, 4))]
+        self.tick = 0
+        self._refill_done = {}
+
+    def before_launch(self) -> int:
+        """Call right before a reset/step launch on the current stream; returns its tick."""
+        ev = self._refill_done.pop(self.tick - self.delay, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return self.tick
+
+    def after_launch(self) -> None:
+        """Call right after the launch: queue the refill behind it on the side stream."""
+        launched = torch.cuda.Event()
+        launched.record(torch.cuda.current_stream())
+        side = self.sides[self.tick % len(self.sides)]  # consecutive refills overlap each other
+        side.wait_event(launched)
+        with torch.cuda.stream(side):
+            stash_refill(self.stash, self.m)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._refill_done[self.tick] = done
+        self.tick += 1
+
+    def drain(self) -> None:
+        """Make the current stream wait for every refill in flight (before freeing buffers)."""
+        for ev in self._refill_done.values():
+            torch.cuda.current_stream().wait_event(ev)
+        self._refill_done.clear()
+
+
+class StepLoop:
+    """An in-place random-policy stepping loop with every launch descriptor built once
+    ({ rbg_random_actions; rbg_connector_step[_prefetch] } per step + rbg_stash_refill): what a
+    training loop that reuses its buffers looks like from the host.  The validated, allocating
+    path is connector_step(); this class only removes per-call Python work (tensor checks,
+    ctypes struct construction), which at B = 4096 costs more than the kernels themselves.
+
+    refill_every = K > 0 turns on the next-episode stash (include/rbg_prw.h::rbg_stash) in its
+    epoch form: launches are grouped in epochs of K ticks; ONE refill runs on a side stream after
+    the last launch of each epoch e and must be complete before the first launch of epoch e + 2
+    (one stream event per epoch instead of four API calls per step).  An entry requested in epoch
+    e is therefore usable from tick K * (e + 2) on, which is what the launches write to ready_at.
+    All main-stream launches go to the stream that was current at construction."""
+
+    def __init__(self, state: StateBufs, timestep: TimestepBufs, policy_keys: torch.Tensor,
+                 time_limit: int = 50, timestep_reward: float = -0.03,
+                 connected_reward: float = 0.1, refill_every: int = 0,
+                 fuse_policy: bool = False) -> None:
+        B, m, _ = state["grid"].shape
+        N = state["start"].shape[1]
+        dev = state["grid"].device
+        self.B, self.m, self.N, self.dev = B, m, N, dev
+        self.state, self.timestep = state, timestep
+        self.keys = check_keys(policy_keys)
+        self.action = torch.empty((B, N), dtype=torch.int32, device=dev)
+        self._lib = nat.lib()
+        self._s = _state_struct(state, B, m, N)
+        self._t = _timestep_struct(timestep, B, m, N)
+        self._p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward), 1)
+        self._main_stream = torch.cuda.current_stream(dev)
+        self._main = C.c_void_p(self._main_stream.cuda_stream)
+        self.K = max(0, int(refill_every))
+        self.fuse_policy = bool(fuse_policy)  # policy + step in ONE launch (rollout of 1 step)
+        self.tick = 0
+        if self.K:
+            self.stash = alloc_stash(B, m, N, dev)
+            self._h = _stash_struct(self.stash, B, m, N)
+            # consecutive refills may overlap each other (each keeps only a few waves busy)
+            self._sides = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            self._launched = [torch.cuda.Event() for _ in range(4)]
+            self._done = [torch.cuda.Event() for _ in range(4)]
+
+    # -- stash protocol ----------------------------------------------------------------------
+    def _ready_delay(self) -> int:
+        K = self.K
+        return K * (self.tick // K + 2) - self.tick
+
+    def _before_launch(self) -> None:
+        K, e = self.K, self.tick // self.K
+        if self.tick % K == 0 and e >= 2:  # first launch of epoch e needs the refill of epoch e-2
+            self._main_stream.wait_event(self._done[(e - 2) % 4])
+
+    def _after_launch(self) -> None:
+        K, e = self.K, self.tick // self.K
+        if self.tick % K == K - 1:  # last launch of epoch e: queue its refill on a side stream
+            side = self._sides[e % 2]
+            ev = self._launched[e % 4]
+            ev.record(self._main_stream)
+            side.wait_event(ev)
+            nat.check(self._lib.rbg_stash_refill(self.B, self.m, self.N, C.byref(self._h),
+                                                 C.c_void_p(side.cuda_stream)), "rbg_stash_refill")
+            self._done[e % 4].record(side)
+        self.tick += 1
+
+    # -- launches ------------------------------------------------------------------------------
+    def reset(self, keys: torch.Tensor) -> None:
+        """env.reset(keys) into the loop's buffers."""
+        keys = check_keys(keys)
+        if self.K:
+            self._before_launch()
+            nat.check(self._lib.rbg_connector_reset_prefetch(
+                keys.data_ptr(), self.B, self.m, self.N, C.byref(self._s), C.byref(self._t),
+                C.byref(self._h), self.tick, self._ready_delay(), self._main),
+                "rbg_connector_reset_prefetch")
+            self._after_launch()
+        else:
+            nat.check(self._lib.rbg_connector_reset(
+                keys.data_ptr(), self.B, self.m, self.N, C.byref(self._s), C.byref(self._t),
+                self._main), "rbg_connector_reset")
+
+    def step(self, t: int) -> None:
+        """Policy at global step t, then one auto-resetting env step, in place."""
+        lib = self._lib
+        if self.fuse_policy:
+            if self.K:
+                self._before_launch()
+            rc = lib.rbg_connector_rollout_prefetch(
+                self.B, self.m, self.N, C.byref(self._s), C.byref(self._s), self.keys.data_ptr(),
+                int(t) & 0xFFFFFFFF, 1, C.byref(self._p), None, C.byref(self._t),
+                C.byref(self._h) if self.K else None, self.tick,
+                self._ready_delay() if self.K else 0, self._main)
+            if rc:
+                nat.check(rc, "rbg_connector_rollout_prefetch")
+            if self.K:
+                self._after_launch()
+            return
+        rc = lib.rbg_random_actions(self.keys.data_ptr(), self.B, self.N, int(t) & 0xFFFFFFFF,
+                                    self.timestep["action_mask"].data_ptr(),
+                                    self.action.data_ptr(), self._main)
+        if rc:
+            nat.check(rc, "rbg_random_actions")
+        if self.K:
+            self._before_launch()
+            rc = lib.rbg_connector_step_prefetch(
+                self.B, self.m, self.N, C.byref(self._s), C.byref(self._s), self.action.data_ptr(),
+                C.byref(self._p), C.byref(self._t), C.byref(self._h), self.tick,
+                self._ready_delay(), self._main)
+            if rc:
+                nat.check(rc, "rbg_connector_step_prefetch")
+            self._after_launch()
+        else:
+            rc = lib.rbg_connector_step(self.B, self.m, self.N, C.byref(self._s), C.byref(self._s),
+                                        self.action.data_ptr(), C.byref(self._p),
+                                        C.byref(self._t), self._main)
+            if rc:
+                nat.check(rc, "rbg_connector_step")
+
+    def drain(self) -> None:
+        """Make the main stream wait for every refill in flight (before freeing the buffers)."""
+        if self.K:
+            for side in self._sides:
+                self._main_stream.wait_stream(side)
+
+
 ROLLOUT_STATS = ("episodes", "connections_made", "unconnected_agent_steps", "final_connections",
                  "final_path_length")
 

@@ -530,3 +530,96 @@ def test_c_api_demo_program(oracle, tmp_path):
     assert f"walk_iters_sum {int(iters.sum())} " in out, out
     assert f"solved_fnv1a {fnv:016x}" in out, out
     assert "rollout 50 steps: episodes" in out
+
+
+# ------------------------------------------------------------------------------ prefetched resets
+@pytest.mark.parametrize("delay", [1, 4])
+def test_prefetched_auto_reset_matches_oracle(rbg, oracle, delay):
+    """VmapAutoResetWrapper(prefetch=True): next-episode States come from the side-stream stash;
+    every state and timestep must equal the inline path (= the oracle), and the stash must
+    actually be hit once it is warm."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, steps, tl = 16, 10, 256, 70, 12
+    env = rbg.VmapAutoResetWrapper(
+        rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), time_limit=tl),
+        prefetch=True, prefetch_delay=delay)
+    keys, akeys = _keys(rbg, 51, B), _keys(rbg, 52, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle.connector_reset_batch(to_np(keys), m, N, threads=8)
+    n_last = 0
+    for t in range(steps):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        state, ts = env.step(state, action)
+        ets = oracle.connector_step_batch(est, eaction, time_limit=tl, auto_reset=True, threads=8)
+        assert_dicts_equal(state_to_np(state), est, f"step {t} state.")
+        assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
+        n_last += int(to_np(ts.last()).sum())
+    hits = int(to_np(env.unwrapped._prefetcher.stash["hits"]).sum())
+    assert n_last > 2 * B
+    # episodes last >= 1 step and at most `tl`: with delay <= 4 nearly every reset is a stash hit
+    assert hits >= 0.9 * n_last, (hits, n_last)
+    env.unwrapped._prefetcher.drain()
+
+
+def test_prefetched_auto_reset_async_stress(rbg, torch_mod):
+    """400 steps of 4096 envs without any host synchronisation (refills genuinely overlap later
+    steps): the prefetching path must end in exactly the state of the inline path."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, steps, tl = 16, 10, 4096, 400, 9
+    keys, akeys = _keys(rbg, 61, B), _keys(rbg, 62, B)
+    st_a, ts_a = ops.connector_reset(keys, m, N)
+    act = torch_mod.empty((B, N), dtype=torch_mod.int32, device="cuda")
+    for t in range(steps):
+        ops.random_actions(akeys, t, ts_a["action_mask"], out=act)
+        ops.connector_step(st_a, act, time_limit=tl, auto_reset=True, state_out=st_a, timestep=ts_a)
+    pf = ops.Prefetcher(B, m, N, keys.device, delay=3)
+    tick = pf.before_launch()
+    st_b, ts_b = ops.connector_reset_prefetch(keys, m, N, pf.stash, tick, pf.delay)
+    pf.after_launch()
+    for t in range(steps):
+        ops.random_actions(akeys, t, ts_b["action_mask"], out=act)
+        tick = pf.before_launch()
+        ops.connector_step_prefetch(st_b, act, pf.stash, tick, pf.delay, time_limit=tl,
+                                    state_out=st_b, timestep=ts_b)
+        pf.after_launch()
+    pf.drain()
+    torch_mod.cuda.synchronize()
+    for k in ("grid", "step_count", "start", "target", "position"):
+        assert torch_mod.equal(st_a[k], st_b[k]), k
+    assert torch_mod.equal(st_a["key"].view(torch_mod.int32), st_b["key"].view(torch_mod.int32))
+    assert torch_mod.equal(ts_a["obs_grid"], ts_b["obs_grid"])
+    assert torch_mod.equal(ts_a["reward"], ts_b["reward"])
+    hits = int(pf.stash["hits"].sum().item())
+    assert hits > 10 * B, hits
+
+
+@pytest.mark.parametrize("K,fuse", [(0, False), (3, False), (3, True), (0, True), (5, True)])
+def test_step_loop_equals_validated_path(rbg, torch_mod, K, fuse):
+    """ops.StepLoop (prebuilt launch descriptors, optional epoch stash, optional fused policy) is
+    the same function as { random_actions; connector_step(auto_reset) } step by step."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, steps, tl = 16, 10, 1024, 150, 11
+    keys, pkeys = _keys(rbg, 71, B), _keys(rbg, 72, B)
+    ref, rts = ops.connector_reset(keys, m, N)
+    for t in range(steps):
+        act = ops.random_actions(pkeys, t, rts["action_mask"])
+        ref, rts = ops.connector_step(ref, act, time_limit=tl, auto_reset=True)
+    st, ts = ops.alloc_state(B, m, N, "cuda"), ops.alloc_timestep(B, m, N, "cuda")
+    loop = ops.StepLoop(st, ts, pkeys, time_limit=tl, refill_every=K, fuse_policy=fuse)
+    loop.reset(keys)
+    for t in range(steps):
+        loop.step(t)
+    loop.drain()
+    torch_mod.cuda.synchronize()
+    for k in ("grid", "step_count", "start", "target", "position"):
+        assert torch_mod.equal(st[k], ref[k]), k
+    assert torch_mod.equal(st["key"].view(torch_mod.int32), ref["key"].view(torch_mod.int32))
+    for k in ("obs_grid", "action_mask", "reward", "discount", "step_type", "num_connections",
+              "total_path_length"):
+        assert torch_mod.equal(ts[k], rts[k]), k
+    if K:
+        assert int(loop.stash["hits"].sum().item()) > B
