@@ -110,6 +110,9 @@ def main() -> None:
     ap.add_argument("--rehearse-single-gpu", action="store_true",
                     help="developer option: run all ranks on GPU 0 over gloo to rehearse the "
                          "multi-rank path on a one-GPU box (numbers are meaningless)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="developer option: join a process group even with one rank, so that a "
+                         "one-GPU box exercises RCCL init / barrier / all-reduce")
     ap.add_argument("--stream-batch", type=int, default=65536,
                     help="batch of the pure-step HBM streaming check (0 = skip)")
     ap.add_argument("--rollout-steps", type=int, default=50,
@@ -127,7 +130,7 @@ def main() -> None:
 
     rank, local_rank, world = sharding.init_distributed(
         backend="gloo" if args.rehearse_single_gpu else None,
-        single_device=args.rehearse_single_gpu)
+        single_device=args.rehearse_single_gpu, force=args.force_process_group)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with "
                          "torch.distributed.run --nproc-per-node N")
@@ -139,11 +142,11 @@ def main() -> None:
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if world > 1:  # the first collective pays communicator setup: keep it out of the timed region
+    if dist.is_initialized():  # the first collective pays communicator setup: keep it out of the timed region
         sharding.all_reduce_metrics({"boards": 0.0}, device=dev)
 
     # ---------------------------------------------------------------- inputs resident in HBM
@@ -197,19 +200,21 @@ def main() -> None:
     # ---------------------------------------------------------------- secondary: env.step rollout
     # BASELINE configs[2] through the per-step API: every step = masked-uniform policy kernel +
     # connector_kernel (state in/out + full observation through HBM), auto-reset on.  The loop
-    # reuses its buffers and prebuilt launch descriptors (ops.StepLoop).  Three variants:
+    # reuses its buffers and prebuilt launch descriptors (ops.StepLoop).  Four variants:
     #   prefetch     next-episode States generated ahead of time on a side stream (rbg_stash),
     #                so a step launch never waits for a random walk           -> `value`
     #   inline       the walk of every finished env runs inside the step launch
     #   fused_policy prefetch + policy and step in one launch (rbg_connector_rollout, 1 step)
+    #   no_auto_reset  auto-reset off: finished envs stay terminal, no walk ever runs
     env_step = None
     if args.env_steps > 0:
         sb = env_step_bytes(m, N)
 
-        def run_loop(refill_every, fuse):
+        def run_loop(refill_every, fuse, auto_reset=True):
             st = ops.alloc_state(B, m, N, dev)
             ts = ops.alloc_timestep(B, m, N, dev)
-            loop = ops.StepLoop(st, ts, keys, refill_every=refill_every, fuse_policy=fuse)
+            loop = ops.StepLoop(st, ts, keys, refill_every=refill_every, fuse_policy=fuse,
+                                auto_reset=auto_reset)
             loop.reset(keys)
             for t in range(30):
                 loop.step(t)
@@ -230,14 +235,15 @@ def main() -> None:
         v_pref, k_pref = run_loop(6, False)
         v_inl, k_inl = run_loop(0, False)
         v_fus, k_fus = run_loop(6, True)
+        v_off, k_off = run_loop(0, False, auto_reset=False)
         ach = B * sb / (k_pref * 1e-3) / 1e9
         env_step = {"metric": "env_steps_per_sec", "value": v_pref, "unit": "env-steps/s",
                     "steps": args.env_steps, "auto_reset": True,
                     "policy": "rbg_random_actions (masked uniform), one launch per step",
                     "variants": {"prefetch": v_pref, "inline_reset": v_inl,
-                                 "prefetch_fused_policy": v_fus},
+                                 "prefetch_fused_policy": v_fus, "no_auto_reset": v_off},
                     "ms_per_step": {"prefetch": k_pref, "inline_reset": k_inl,
-                                    "prefetch_fused_policy": k_fus},
+                                    "prefetch_fused_policy": k_fus, "no_auto_reset": k_off},
                     "roofline": {"bound": "hbm", "kernel": "connector_kernel", "achieved": ach,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "traffic": measured_traffic("connector_kernel", B),

@@ -375,7 +375,7 @@ class StepLoop:
     def __init__(self, state: StateBufs, timestep: TimestepBufs, policy_keys: torch.Tensor,
                  time_limit: int = 50, timestep_reward: float = -0.03,
                  connected_reward: float = 0.1, refill_every: int = 0,
-                 fuse_policy: bool = False) -> None:
+                 fuse_policy: bool = False, auto_reset: bool = True) -> None:
         B, m, _ = state["grid"].shape
         N = state["start"].shape[1]
         dev = state["grid"].device
@@ -386,7 +386,8 @@ class StepLoop:
         self._lib = nat.lib()
         self._s = _state_struct(state, B, m, N)
         self._t = _timestep_struct(timestep, B, m, N)
-        self._p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward), 1)
+        self._p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
+                                1 if auto_reset else 0)
         self._main_stream = torch.cuda.current_stream(dev)
         self._main = C.c_void_p(self._main_stream.cuda_stream)
         self.K = max(0, int(refill_every))

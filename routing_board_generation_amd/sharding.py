@@ -23,15 +23,17 @@ SUM_METRICS = ("boards", "env_steps", "episodes", "num_connections", "total_path
 MAX_METRICS = ("max_iters", "elapsed_s")
 
 
-def init_distributed(backend: str = None, single_device: bool = False) -> Tuple[int, int, int]:
+def init_distributed(backend: str = None, single_device: bool = False,
+                     force: bool = False) -> Tuple[int, int, int]:
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run) and joins the
-    process group.  Returns (rank, local_rank, world_size); world_size 1 needs no launcher.
-    single_device=True puts every rank on GPU 0 (a multi-rank rehearsal on a one-GPU box; needs
-    backend="gloo", RCCL refuses two ranks on one device)."""
+    process group.  Returns (rank, local_rank, world_size); world_size 1 needs no launcher and no
+    process group unless force=True (a one-rank RCCL communicator: exercises the collective path
+    on a one-GPU box).  single_device=True puts every rank on GPU 0 (a multi-rank rehearsal on a
+    one-GPU box; needs backend="gloo", RCCL refuses two ranks on one device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if single_device else int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -79,7 +81,7 @@ def all_reduce_metrics(metrics: Dict[str, float], device=None) -> Dict[str, floa
     on CPU).  Keys in SUM_METRICS are summed, keys in MAX_METRICS take the max over ranks."""
     sums = [float(metrics.get(k, 0.0)) for k in SUM_METRICS]
     maxs = [float(metrics.get(k, 0.0)) for k in MAX_METRICS]
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         if dist.get_backend() != "nccl":
             device = torch.device("cpu")  # gloo (CPU tests, single-GPU rehearsals)
         elif device is None:

@@ -623,3 +623,29 @@ def test_step_loop_equals_validated_path(rbg, torch_mod, K, fuse):
         assert torch_mod.equal(ts[k], rts[k]), k
     if K:
         assert int(loop.stash["hits"].sum().item()) > B
+
+
+# ------------------------------------------------------------------------------ bench under RCCL
+def test_bench_under_torchrun_with_a_one_rank_rccl_group():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, backend nccl = RCCL),
+    here with the one rank a one-GPU box allows: communicator init, barrier and the metrics
+    all-reduce run for real, and the line keeps the contract's keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+         "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
+         "--gpus", "1", "--steps", "20", "--warmup", "3", "--env-steps", "20", "--stream-batch",
+         "0", "--rollout-steps", "10", "--cpu-sample", "0", "--force-process-group"],
+        text=True, env=env, cwd=root, timeout=600)
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["value"] > 0
+    assert line["config"]["global_batch"] == 4096
