@@ -232,10 +232,38 @@ def main() -> None:
                                               "elapsed_s": el}, device=dev)
             return em["env_steps"] / em["elapsed_s"], se0.elapsed_time(se1) / args.env_steps
 
-        v_pref, k_pref = run_loop(6, False)
+        def run_api(prefetch, donate):
+            """The same loop through the drop-in classes (State/TimeStep pytrees per step)."""
+            env = rbg.VmapAutoResetWrapper(
+                rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), donate=donate),
+                prefetch=prefetch)
+            state, ts = env.reset(keys)
+            act = torch.empty((B, N), dtype=torch.int32, device=dev)
+            for t in range(30):
+                state, ts = env.step(state, ops.random_actions(keys, t, ts.observation.action_mask,
+                                                               out=act))
+            barrier()
+            t1 = time.perf_counter()
+            for t in range(30, 30 + args.env_steps):
+                state, ts = env.step(state, ops.random_actions(keys, t, ts.observation.action_mask,
+                                                               out=act))
+            barrier()
+            el = time.perf_counter() - t1
+            for sess in env.unwrapped._sessions.values():
+                sess.drain()
+            em = sharding.all_reduce_metrics({"env_steps": float(B * args.env_steps),
+                                              "elapsed_s": el}, device=dev)
+            return em["env_steps"] / em["elapsed_s"]
+
+        v_pref, k_pref = run_loop(8, False)
         v_inl, k_inl = run_loop(0, False)
-        v_fus, k_fus = run_loop(6, True)
+        v_fus, k_fus = run_loop(8, True)
         v_off, k_off = run_loop(0, False, auto_reset=False)
+        api = {"functional": run_api(False, False), "functional_prefetch": run_api(True, False),
+               "donate_prefetch": run_api(True, True),
+               "note": "VmapAutoResetWrapper(Connector(ParallelRandomWalkGenerator)).step with "
+                       "State/TimeStep pytrees; functional = fresh output tensors every step, "
+                       "donate = State advanced in place + two alternating TimeStep buffers"}
         ach = B * sb / (k_pref * 1e-3) / 1e9
         env_step = {"metric": "env_steps_per_sec", "value": v_pref, "unit": "env-steps/s",
                     "steps": args.env_steps, "auto_reset": True,
@@ -244,6 +272,7 @@ def main() -> None:
                                  "prefetch_fused_policy": v_fus, "no_auto_reset": v_off},
                     "ms_per_step": {"prefetch": k_pref, "inline_reset": k_inl,
                                     "prefetch_fused_policy": k_fus, "no_auto_reset": k_off},
+                    "wrapper_api": api,
                     "roofline": {"bound": "hbm", "kernel": "connector_kernel", "achieved": ach,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "traffic": measured_traffic("connector_kernel", B),

@@ -64,9 +64,25 @@ def _make_timestep(ts, batched: bool) -> TimeStep:
                     discount=sel(ts["discount"]), observation=obs, extras=extras)
 
 
+def _state_from_leaves(v, ids: torch.Tensor) -> State:
+    """v in ops.STATE_FIELDS order (batched)."""
+    return State(grid=v[0], step_count=v[1],
+                 agents=Agent(id=ids, start=v[2], target=v[3], position=v[4]), key=v[5])
+
+
+def _timestep_from_leaves(v) -> TimeStep:
+    """v in ops.TIMESTEP_FIELDS order (batched)."""
+    return TimeStep(step_type=v[0], reward=v[1], discount=v[2],
+                    observation=Observation(grid=v[3], action_mask=v[4], step_count=v[5]),
+                    extras={"num_connections": v[6], "ratio_connections": v[7],
+                            "total_path_length": v[8]})
+
+
 class Connector:
     def __init__(self, generator: Optional[Generator] = None, reward_fn: Optional[DenseRewardFn] = None,
-                 time_limit: int = 50, viewer=None) -> None:
+                 time_limit: int = 50, viewer=None, donate: bool = False) -> None:
+        """donate=True (not in jumanji): batched step() advances the State in place and reuses two
+        TimeStep buffer sets alternately instead of allocating outputs (ops.ConnectorSession)."""
         self._generator = generator or UniformRandomGenerator(grid_size=10, num_agents=5)
         self._reward_fn = reward_fn or DenseRewardFn()
         self.time_limit = time_limit
@@ -75,7 +91,8 @@ class Connector:
         self._viewer = viewer
         self._auto_reset = False  # switched on by VmapAutoResetWrapper
         self._prefetch_delay = 0  # > 0: VmapAutoResetWrapper(prefetch=True)
-        self._prefetcher = None
+        self._donate = bool(donate)
+        self._sessions = {}  # (B, device, wrapper + env parameters) -> ops.ConnectorSession
 
     @property
     def unwrapped(self) -> "Connector":
@@ -85,25 +102,31 @@ class Connector:
     def generator(self) -> Generator:
         return self._generator
 
+    def _session(self, B: int, device: torch.device) -> ops.ConnectorSession:
+        """The launch context of batched reset/step calls (ops.ConnectorSession), one per batch
+        size / device / wrapper configuration."""
+        fused_reset = self._auto_reset and isinstance(self._generator, ParallelRandomWalkGenerator)
+        k = (B, device, fused_reset, self._prefetch_delay, self._donate, self.time_limit,
+             self._reward_fn.timestep_reward, self._reward_fn.connected_reward)
+        sess = self._sessions.get(k)
+        if sess is None:
+            sess = self._sessions[k] = ops.ConnectorSession(
+                B, self.grid_size, self.num_agents, device, self.time_limit,
+                self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
+                auto_reset=fused_reset, refill_every=self._prefetch_delay, donate=self._donate)
+        return sess
+
     # ---------------------------------------------------------------------------------- reset
     def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
         batched = key.dim() == 2
         keys = (key if batched else key[None]).contiguous()
         if isinstance(self._generator, ParallelRandomWalkGenerator):
             # fused: walk + State + observation in one launch
-            if self._prefetch_delay > 0 and batched:
-                pf = self._prefetcher
-                if pf is not None:
-                    pf.drain()
-                pf = self._prefetcher = ops.Prefetcher(keys.shape[0], self.grid_size,
-                                                       self.num_agents, keys.device,
-                                                       self._prefetch_delay)
-                tick = pf.before_launch()
-                st, ts = ops.connector_reset_prefetch(keys, self.grid_size, self.num_agents,
-                                                      pf.stash, tick, pf.delay)
-                pf.after_launch()
-            else:
-                st, ts = ops.connector_reset(keys, self.grid_size, self.num_agents)
+            if batched:
+                sess = self._session(keys.shape[0], keys.device)
+                st, ts = sess.reset(keys)
+                return _state_from_leaves(st, sess.agent_ids), _timestep_from_leaves(ts)
+            st, ts = ops.connector_reset(keys, self.grid_size, self.num_agents)
         else:
             st = _state_bufs(self._generator(keys), True)
             ts = ops.connector_observe(st)
@@ -112,20 +135,19 @@ class Connector:
     # ---------------------------------------------------------------------------------- step
     def step(self, state: State, action: torch.Tensor) -> Tuple[State, TimeStep]:
         batched = state.grid.dim() == 3
+        fused_reset = self._auto_reset and isinstance(self._generator, ParallelRandomWalkGenerator)
+        if batched and (fused_reset or not self._auto_reset):
+            # next-episode States come from the session's stash when it holds them (same results
+            # either way)
+            sess = self._session(state.grid.shape[0], state.grid.device)
+            ag = state.agents
+            if action.dtype is not torch.int32:
+                action = action.to(torch.int32)
+            so, ts = sess.step((state.grid, state.step_count, ag.start, ag.target, ag.position,
+                                state.key), action.contiguous())
+            return _state_from_leaves(so, sess.agent_ids), _timestep_from_leaves(ts)
         st = _state_bufs(state, batched)
         act = (action if batched else action[None]).to(torch.int32).contiguous()
-        fused_reset = self._auto_reset and isinstance(self._generator, ParallelRandomWalkGenerator)
-        pf = self._prefetcher
-        if (fused_reset and batched and pf is not None
-                and pf.stash["tag"].shape[0] == st["grid"].shape[0]):
-            # next-episode States come from the stash when it holds them (same results either way)
-            tick = pf.before_launch()
-            so, ts = ops.connector_step_prefetch(st, act, pf.stash, tick, pf.delay,
-                                                 self.time_limit,
-                                                 self._reward_fn.timestep_reward,
-                                                 self._reward_fn.connected_reward)
-            pf.after_launch()
-            return _make_state(so, batched), _make_timestep(ts, batched)
         so, ts = ops.connector_step(st, act, self.time_limit, self._reward_fn.timestep_reward,
                                     self._reward_fn.connected_reward, auto_reset=fused_reset)
         if self._auto_reset and not fused_reset:

@@ -41,13 +41,16 @@ class VmapAutoResetWrapper(_Wrapper):
     the same kernel launch from split(state.key)[0], keeping reward/discount/step_type/extras of
     the terminal step and replacing only the observation."""
 
-    def __init__(self, env, prefetch: bool = False, prefetch_delay: int = 4):
+    def __init__(self, env, prefetch: bool = False, prefetch_delay: int = 8, donate=None):
         """prefetch=True generates every env's NEXT episode ahead of time on a side stream
         (include/rbg_prw.h::rbg_stash), so that a step never waits for a random walk; results are
-        identical with and without it."""
+        identical with and without it.  One refill runs per `prefetch_delay` launches.
+        donate=True/False overrides the env's setting (Connector(donate=...))."""
         super().__init__(env)
         env.unwrapped._auto_reset = True
         env.unwrapped._prefetch_delay = int(prefetch_delay) if prefetch else 0
+        if donate is not None:
+            env.unwrapped._donate = bool(donate)
 
     def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
         if key.dim() != 2:

@@ -19,7 +19,11 @@ TIMESTEP_FIELDS = ("step_type", "reward", "discount", "obs_grid", "action_mask",
 
 
 def _stream(device: torch.device) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """hipStream_t of torch's current stream on `device` (the raw getter costs ~0.3 us,
+    torch.cuda.current_stream(device).cuda_stream ~3.7 us)."""
+    idx = device.index
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(
+        idx if idx is not None else torch.cuda.current_device()))
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -358,6 +362,56 @@ class Prefetcher:
         self._refill_done.clear()
 
 
+class EpochStash:
+    """Host side of the stash protocol in its epoch form: launches are numbered (ticks) and
+    grouped in epochs of K; ONE rbg_stash_refill runs on a side stream after the last launch of
+    each epoch e and must be complete before the first launch of epoch e + 2 (one stream event
+    per epoch instead of four API calls per step).  An entry requested in epoch e is therefore
+    usable from tick K * (e + 2) on, which is what the launches write to ready_at."""
+
+    def __init__(self, B: int, m: int, N: int, device, every: int) -> None:
+        self.B, self.m, self.N, self.device = B, m, N, device
+        self.K = max(1, int(every))
+        self.tick = 0
+        self.stash = alloc_stash(B, m, N, device)
+        self.struct = _stash_struct(self.stash, B, m, N)
+        self._lib = nat.lib()
+        # consecutive refills may overlap each other (each keeps only a few waves busy)
+        self._sides = [torch.cuda.Stream(device=device) for _ in range(2)]
+        self._launched = [torch.cuda.Event() for _ in range(4)]
+        self._done = [torch.cuda.Event() for _ in range(4)]
+
+    def ready_delay(self) -> int:
+        K = self.K
+        return K * (self.tick // K + 2) - self.tick
+
+    def before_launch(self, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Right before a reset/step launch on `stream` (default: torch's current stream)."""
+        K, e = self.K, self.tick // self.K
+        if self.tick % K == 0 and e >= 2:  # first launch of epoch e needs the refill of epoch e-2
+            (stream or torch.cuda.current_stream(self.device)).wait_event(self._done[(e - 2) % 4])
+
+    def after_launch(self, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Right after it: the last launch of an epoch queues the refill on a side stream."""
+        K, e = self.K, self.tick // self.K
+        if self.tick % K == K - 1:
+            stream = stream or torch.cuda.current_stream(self.device)
+            side = self._sides[e % 2]
+            ev = self._launched[e % 4]
+            ev.record(stream)
+            side.wait_event(ev)
+            nat.check(self._lib.rbg_stash_refill(self.B, self.m, self.N, C.byref(self.struct),
+                                                 C.c_void_p(side.cuda_stream)), "rbg_stash_refill")
+            self._done[e % 4].record(side)
+        self.tick += 1
+
+    def drain(self, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Make `stream` wait for every refill in flight (before freeing the buffers)."""
+        stream = stream or torch.cuda.current_stream(self.device)
+        for side in self._sides:
+            stream.wait_stream(side)
+
+
 class StepLoop:
     """An in-place random-policy stepping loop with every launch descriptor built once
     ({ rbg_random_actions; rbg_connector_step[_prefetch] } per step + rbg_stash_refill): what a
@@ -365,12 +419,9 @@ class StepLoop:
     path is connector_step(); this class only removes per-call Python work (tensor checks,
     ctypes struct construction), which at B = 4096 costs more than the kernels themselves.
 
-    refill_every = K > 0 turns on the next-episode stash (include/rbg_prw.h::rbg_stash) in its
-    epoch form: launches are grouped in epochs of K ticks; ONE refill runs on a side stream after
-    the last launch of each epoch e and must be complete before the first launch of epoch e + 2
-    (one stream event per epoch instead of four API calls per step).  An entry requested in epoch
-    e is therefore usable from tick K * (e + 2) on, which is what the launches write to ready_at.
-    All main-stream launches go to the stream that was current at construction."""
+    refill_every = K > 0 turns on the next-episode stash (include/rbg_prw.h::rbg_stash) with the
+    epoch protocol of EpochStash.  All main-stream launches go to the stream that was current at
+    construction."""
 
     def __init__(self, state: StateBufs, timestep: TimestepBufs, policy_keys: torch.Tensor,
                  time_limit: int = 50, timestep_reward: float = -0.03,
@@ -392,36 +443,22 @@ class StepLoop:
         self._main = C.c_void_p(self._main_stream.cuda_stream)
         self.K = max(0, int(refill_every))
         self.fuse_policy = bool(fuse_policy)  # policy + step in ONE launch (rollout of 1 step)
-        self.tick = 0
+        self._epochs = EpochStash(B, m, N, dev, self.K) if self.K else None
         if self.K:
-            self.stash = alloc_stash(B, m, N, dev)
-            self._h = _stash_struct(self.stash, B, m, N)
-            # consecutive refills may overlap each other (each keeps only a few waves busy)
-            self._sides = [torch.cuda.Stream(device=dev) for _ in range(2)]
-            self._launched = [torch.cuda.Event() for _ in range(4)]
-            self._done = [torch.cuda.Event() for _ in range(4)]
+            self.stash, self._h = self._epochs.stash, self._epochs.struct
 
-    # -- stash protocol ----------------------------------------------------------------------
+    @property
+    def tick(self) -> int:
+        return self._epochs.tick if self._epochs else 0
+
     def _ready_delay(self) -> int:
-        K = self.K
-        return K * (self.tick // K + 2) - self.tick
+        return self._epochs.ready_delay()
 
     def _before_launch(self) -> None:
-        K, e = self.K, self.tick // self.K
-        if self.tick % K == 0 and e >= 2:  # first launch of epoch e needs the refill of epoch e-2
-            self._main_stream.wait_event(self._done[(e - 2) % 4])
+        self._epochs.before_launch(self._main_stream)
 
     def _after_launch(self) -> None:
-        K, e = self.K, self.tick // self.K
-        if self.tick % K == K - 1:  # last launch of epoch e: queue its refill on a side stream
-            side = self._sides[e % 2]
-            ev = self._launched[e % 4]
-            ev.record(self._main_stream)
-            side.wait_event(ev)
-            nat.check(self._lib.rbg_stash_refill(self.B, self.m, self.N, C.byref(self._h),
-                                                 C.c_void_p(side.cuda_stream)), "rbg_stash_refill")
-            self._done[e % 4].record(side)
-        self.tick += 1
+        self._epochs.after_launch(self._main_stream)
 
     # -- launches ------------------------------------------------------------------------------
     def reset(self, keys: torch.Tensor) -> None:
@@ -479,8 +516,141 @@ class StepLoop:
     def drain(self) -> None:
         """Make the main stream wait for every refill in flight (before freeing the buffers)."""
         if self.K:
-            for side in self._sides:
-                self._main_stream.wait_stream(side)
+            self._epochs.drain(self._main_stream)
+
+
+
+class ConnectorSession:
+    """Launch context of the allocating (functional) reset / step for one (B, m, N, device) and
+    one set of env parameters: what Connector keeps between calls so that a step costs the host
+    little more than allocating its outputs (at B = 4096 the checked path below costs more host
+    time than the kernels take).  Output tensors are allocated here, so their pointer structs
+    are built without re-validation, and the State returned last is remembered by tensor
+    identity: feeding it to the next step -- the shape of every rollout loop -- skips validating
+    the input too.  Any other State goes through the checked path.  refill_every = K > 0 adds
+    the next-episode stash with the epoch protocol of EpochStash.
+
+    donate=True gives up the functional style for speed, like jax's donate_argnums: step()
+    advances the State it is given IN PLACE (and returns the same tensors), and the TimeStep
+    lands in one of two buffer sets used alternately -- the timestep returned by a step stays
+    intact during the next step and is overwritten by the one after.  No allocation per step."""
+
+    def __init__(self, B: int, m: int, N: int, device, time_limit: int = 50,
+                 timestep_reward: float = -0.03, connected_reward: float = 0.1,
+                 auto_reset: bool = False, refill_every: int = 0, donate: bool = False) -> None:
+        self.B, self.m, self.N, self.device = B, m, N, device
+        self.donate = bool(donate)
+        self._ring, self._ring_i = None, 0
+        self._lib = nat.lib()
+        self._p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
+                                1 if auto_reset else 0)
+        self.K = max(0, int(refill_every)) if auto_reset else 0
+        self.epochs = None
+        self._last = None  # (leaves in STATE_FIELDS order, nat.State) of the State returned last
+        self.agent_ids = torch.arange(N, dtype=torch.int32, device=device).expand(B, N)
+        # Outputs are carved from chunks that hold `chunk_steps` steps per field (one torch.empty
+        # + one unbind per field and chunk instead of 15 torch.empty per step, which alone cost
+        # ~25 us of host time).  Every step still gets memory of its own; a tensor kept alive
+        # keeps its chunk alive, so chunks are capped at ~256 MB per field.
+        i32, f32 = torch.int32, torch.float32
+        self._specs = (
+            ("grid", i32, (B, m, m)), ("step_count", i32, (B,)), ("start", i32, (B, N, 2)),
+            ("target", i32, (B, N, 2)), ("position", i32, (B, N, 2)), ("key", torch.uint32, (B, 2)),
+            ("step_type", torch.int8, (B,)), ("reward", f32, (B, N)), ("discount", f32, (B, N)),
+            ("obs_grid", i32, (B, N, m, m)), ("action_mask", torch.bool, (B, N, 5)),
+            ("obs_step_count", i32, (B,)), ("num_connections", i32, (B,)),
+            ("ratio_connections", f32, (B,)), ("total_path_length", i32, (B,)))
+        self.chunk_steps = max(1, min(16, (256 << 20) // (4 * B * N * m * m)))
+        self._views, self._bases, self._cursor = None, None, 0
+
+    def _fresh(self):
+        """(state leaves, nat.State, timestep leaves, nat.Timestep) of the next step's outputs;
+        leaves in STATE_FIELDS / TIMESTEP_FIELDS order."""
+        i = self._cursor
+        if self._views is None or i == self.chunk_steps:
+            S, dev = self.chunk_steps, self.device
+            chunks = [torch.empty((S,) + shape, dtype=dt, device=dev) for _, dt, shape in self._specs]
+            self._views = list(zip(*[c.unbind(0) for c in chunks]))  # [step][field]
+            self._bases = [(c.data_ptr(), c[0].numel() * c.element_size()) for c in chunks]
+            i = 0
+        self._cursor = i + 1
+        v = self._views[i]
+        ptrs = [base + i * nbytes for base, nbytes in self._bases]
+        return v[:6], nat.State(*ptrs[:6]), v[6:], nat.Timestep(*ptrs[6:])
+
+    def _outputs(self, in_leaves=None, in_struct=None):
+        """Where a launch writes: fresh memory, or with donate the input State + the ring."""
+        if not self.donate:
+            return self._fresh()
+        if self._ring is None:
+            self._ring = []
+            for _ in range(2):
+                ts = alloc_timestep(self.B, self.m, self.N, self.device)
+                v = tuple(ts[f] for f in TIMESTEP_FIELDS)
+                self._ring.append((v, nat.Timestep(*[x.data_ptr() for x in v])))
+        self._ring_i ^= 1
+        tv, t = self._ring[self._ring_i]
+        if in_leaves is None:  # reset
+            st = alloc_state(self.B, self.m, self.N, self.device)
+            in_leaves = tuple(st[f] for f in STATE_FIELDS)
+            in_struct = nat.State(*[x.data_ptr() for x in in_leaves])
+        return in_leaves, in_struct, tv, t
+
+    def reset(self, keys: torch.Tensor):
+        keys = check_keys(keys)
+        if keys.shape[0] != self.B or keys.device != self.agent_ids.device:
+            raise ValueError("keys do not match this session's batch size / device")
+        st, s, ts, t = self._outputs()
+        if self.K:
+            if self.epochs is not None:
+                self.epochs.drain()
+            ep = self.epochs = EpochStash(self.B, self.m, self.N, self.device, self.K)
+            ep.before_launch()
+            rc = self._lib.rbg_connector_reset_prefetch(
+                keys.data_ptr(), self.B, self.m, self.N, C.byref(s), C.byref(t),
+                C.byref(ep.struct), ep.tick, ep.ready_delay(), _stream(self.device))
+            ep.after_launch()
+        else:
+            rc = self._lib.rbg_connector_reset(keys.data_ptr(), self.B, self.m, self.N,
+                                               C.byref(s), C.byref(t), _stream(self.device))
+        if rc:
+            nat.check(rc, "rbg_connector_reset")
+        self._last = (st, s)
+        return st, ts
+
+    def step(self, leaves, action: torch.Tensor):
+        """leaves = (grid, step_count, start, target, position, key) of a batched State."""
+        last = self._last
+        if (last is not None and leaves[0] is last[0][0] and leaves[1] is last[0][1]
+                and leaves[2] is last[0][2] and leaves[3] is last[0][3]
+                and leaves[4] is last[0][4] and leaves[5] is last[0][5]):
+            si = last[1]
+        else:
+            held = {f: x.contiguous() for f, x in zip(STATE_FIELDS, leaves)}  # alive till launch
+            si = _state_struct(held, self.B, self.m, self.N)
+            leaves = tuple(held[f] for f in STATE_FIELDS)
+        _check(action, torch.int32, (self.B, self.N), "action")
+        st, s, ts, t = self._outputs(leaves, si)
+        ep = self.epochs
+        if ep is not None:
+            ep.before_launch()
+            rc = self._lib.rbg_connector_step_prefetch(
+                self.B, self.m, self.N, C.byref(si), C.byref(s), action.data_ptr(),
+                C.byref(self._p), C.byref(t), C.byref(ep.struct), ep.tick, ep.ready_delay(),
+                _stream(self.device))
+            ep.after_launch()
+        else:
+            rc = self._lib.rbg_connector_step(
+                self.B, self.m, self.N, C.byref(si), C.byref(s), action.data_ptr(),
+                C.byref(self._p), C.byref(t), _stream(self.device))
+        if rc:
+            nat.check(rc, "rbg_connector_step")
+        self._last = (st, s)
+        return st, ts
+
+    def drain(self) -> None:
+        if self.epochs is not None:
+            self.epochs.drain()
 
 
 ROLLOUT_STATS = ("episodes", "connections_made", "unconnected_agent_steps", "final_connections",

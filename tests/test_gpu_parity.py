@@ -556,11 +556,41 @@ def test_prefetched_auto_reset_matches_oracle(rbg, oracle, delay):
         assert_dicts_equal(state_to_np(state), est, f"step {t} state.")
         assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
         n_last += int(to_np(ts.last()).sum())
-    hits = int(to_np(env.unwrapped._prefetcher.stash["hits"]).sum())
+    (sess,) = env.unwrapped._sessions.values()
+    hits = int(to_np(sess.epochs.stash["hits"]).sum())
     assert n_last > 2 * B
-    # episodes last >= 1 step and at most `tl`: with delay <= 4 nearly every reset is a stash hit
+    # an entry is usable at most 2 * delay launches after it was requested and nearly every
+    # episode runs to the time limit of 12 steps: nearly every reset is a stash hit
     assert hits >= 0.9 * n_last, (hits, n_last)
-    env.unwrapped._prefetcher.drain()
+    sess.drain()
+
+
+def test_step_accepts_states_it_did_not_return(rbg, torch_mod):
+    """Connector.step recognises the State it returned last by tensor identity and skips
+    re-validating it; any other State (here: clones, and a State from two steps ago) takes the
+    checked path.  Same function either way."""
+    from routing_board_generation_amd import ops
+    from routing_board_generation_amd.types import Agent, State
+
+    m, N, B = 10, 5, 300
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N),
+                                                 time_limit=9))
+    keys, akeys = _keys(rbg, 81, B), _keys(rbg, 82, B)
+    s0, ts0 = env.reset(keys)
+    a0 = ops.random_actions(akeys, 0, ts0.observation.action_mask)
+    s1, ts1 = env.step(s0, a0)                      # fast path (s0 was returned last)
+    a1 = ops.random_actions(akeys, 1, ts1.observation.action_mask)
+    s2, ts2 = env.step(s1, a1)                      # fast path
+    clone = State(grid=s1.grid.clone(), step_count=s1.step_count.clone(),
+                  agents=Agent(*[x.clone() for x in s1.agents]), key=s1.key.clone())
+    s2c, ts2c = env.step(clone, a1.to(torch_mod.int64))   # checked path, action cast to int32
+    s1b, ts1b = env.step(s0, a0)                    # checked path: s0 is no longer the last one
+    for a, b in ((s2, s2c), (s1, s1b)):
+        assert_dicts_equal(state_to_np(a), state_to_np(b), "state.")
+    for a, b in ((ts2, ts2c), (ts1, ts1b)):
+        assert_dicts_equal(timestep_to_np(a), timestep_to_np(b), "timestep.")
+    with pytest.raises(ValueError):
+        env.step(s1, a1[:, :3])
 
 
 def test_prefetched_auto_reset_async_stress(rbg, torch_mod):
@@ -649,3 +679,34 @@ def test_bench_under_torchrun_with_a_one_rank_rccl_group():
         assert k in line, k
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["value"] > 0
     assert line["config"]["global_batch"] == 4096
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_donated_stepping_matches_oracle(rbg, oracle, prefetch):
+    """Connector(donate=True): the State is advanced in place and the TimeStep alternates between
+    two buffer sets; values equal the functional path (= the oracle) step by step, and the
+    timestep of step t is still intact after step t + 1."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, steps, tl = 12, 6, 200, 40, 10
+    env = rbg.VmapAutoResetWrapper(
+        rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), time_limit=tl, donate=True),
+        prefetch=prefetch, prefetch_delay=3)
+    keys, akeys = _keys(rbg, 91, B), _keys(rbg, 92, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle.connector_reset_batch(to_np(keys), m, N, threads=8)
+    grid_ptr = state.grid.data_ptr()
+    prev_ts, prev_ets = None, None
+    for t in range(steps):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        state, ts = env.step(state, action)
+        ets = oracle.connector_step_batch(est, eaction, time_limit=tl, auto_reset=True, threads=8)
+        assert state.grid.data_ptr() == grid_ptr
+        assert_dicts_equal(state_to_np(state), est, f"step {t} state.")
+        assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
+        if prev_ts is not None:
+            assert_dicts_equal(timestep_to_np(prev_ts), prev_ets, f"step {t - 1} timestep, kept.")
+        prev_ts, prev_ets = ts, {k: np.copy(v) for k, v in ets.items()}
+    for sess in env.unwrapped._sessions.values():
+        sess.drain()
