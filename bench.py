@@ -232,11 +232,12 @@ def main() -> None:
                                               "elapsed_s": el}, device=dev)
             return em["env_steps"] / em["elapsed_s"], se0.elapsed_time(se1) / args.env_steps
 
-        def run_api(prefetch, donate):
+        def run_api(prefetch, donate, single_agent=False):
             """The same loop through the drop-in classes (State/TimeStep pytrees per step)."""
-            env = rbg.VmapAutoResetWrapper(
-                rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), donate=donate),
-                prefetch=prefetch)
+            env = rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), donate=donate)
+            if single_agent:  # the reference's training env (setup_train.py:158-167)
+                env = rbg.MultiToSingleWrapper(env)
+            env = rbg.VmapAutoResetWrapper(env, prefetch=prefetch)
             state, ts = env.reset(keys)
             act = torch.empty((B, N), dtype=torch.int32, device=dev)
             for t in range(30):
@@ -261,6 +262,7 @@ def main() -> None:
         v_off, k_off = run_loop(0, False, auto_reset=False)
         api = {"functional": run_api(False, False), "functional_prefetch": run_api(True, False),
                "donate_prefetch": run_api(True, True),
+               "donate_prefetch_multi_to_single": run_api(True, True, single_agent=True),
                "note": "VmapAutoResetWrapper(Connector(ParallelRandomWalkGenerator)).step with "
                        "State/TimeStep pytrees; functional = fresh output tensors every step, "
                        "donate = State advanced in place + two alternating TimeStep buffers"}

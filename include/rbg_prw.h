@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 1
+#define RBG_ABI_VERSION 2
 
 #define RBG_E_NULL (-1)   /* a required pointer is NULL */
 #define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
@@ -64,6 +64,11 @@ typedef struct rbg_timestep {
   int32_t *num_connections;   /* [B] */
   float *ratio_connections;   /* [B] */
   int32_t *total_path_length; /* [B] */
+  /* [3P] jumanji.wrappers.MultiToSingleWrapper (setup_train.py:158-161) applied inside the
+   * launch: reward summed over the agents in float32, agent 0 first ((0 + r_0) + r_1) + ...,
+   * and the largest per-agent discount. */
+  float *reward_total;        /* [B] */
+  float *discount_max;        /* [B] */
 } rbg_timestep;
 
 /* [3P] Connector.__init__(time_limit=50) + DenseRewardFn(timestep_reward, connected_reward) +

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
 HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
                "-std=c++17"]
 
@@ -32,7 +32,8 @@ class Timestep(C.Structure):
     _fields_ = [("step_type", C.c_void_p), ("reward", C.c_void_p), ("discount", C.c_void_p),
                 ("obs_grid", C.c_void_p), ("action_mask", C.c_void_p),
                 ("obs_step_count", C.c_void_p), ("num_connections", C.c_void_p),
-                ("ratio_connections", C.c_void_p), ("total_path_length", C.c_void_p)]
+                ("ratio_connections", C.c_void_p), ("total_path_length", C.c_void_p),
+                ("reward_total", C.c_void_p), ("discount_max", C.c_void_p)]
 
 
 class RolloutStats(C.Structure):

@@ -71,8 +71,10 @@ def _state_from_leaves(v, ids: torch.Tensor) -> State:
 
 
 def _timestep_from_leaves(v) -> TimeStep:
-    """v in ops.TIMESTEP_FIELDS order (batched)."""
-    return TimeStep(step_type=v[0], reward=v[1], discount=v[2],
+    """v in ops.TIMESTEP_FIELDS order (batched); the aggregated reward / discount stand in for
+    the per-agent ones when the session produced those (MultiToSingleWrapper)."""
+    return TimeStep(step_type=v[0], reward=v[1] if v[1] is not None else v[9],
+                    discount=v[2] if v[2] is not None else v[10],
                     observation=Observation(grid=v[3], action_mask=v[4], step_count=v[5]),
                     extras={"num_connections": v[6], "ratio_connections": v[7],
                             "total_path_length": v[8]})
@@ -92,6 +94,7 @@ class Connector:
         self._auto_reset = False  # switched on by VmapAutoResetWrapper
         self._prefetch_delay = 0  # > 0: VmapAutoResetWrapper(prefetch=True)
         self._donate = bool(donate)
+        self._aggregate = False  # switched on by MultiToSingleWrapper
         self._sessions = {}  # (B, device, wrapper + env parameters) -> ops.ConnectorSession
 
     @property
@@ -106,14 +109,16 @@ class Connector:
         """The launch context of batched reset/step calls (ops.ConnectorSession), one per batch
         size / device / wrapper configuration."""
         fused_reset = self._auto_reset and isinstance(self._generator, ParallelRandomWalkGenerator)
-        k = (B, device, fused_reset, self._prefetch_delay, self._donate, self.time_limit,
+        k = (B, device, fused_reset, self._prefetch_delay, self._donate, self._aggregate,
+             self.time_limit,
              self._reward_fn.timestep_reward, self._reward_fn.connected_reward)
         sess = self._sessions.get(k)
         if sess is None:
             sess = self._sessions[k] = ops.ConnectorSession(
                 B, self.grid_size, self.num_agents, device, self.time_limit,
                 self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
-                auto_reset=fused_reset, refill_every=self._prefetch_delay, donate=self._donate)
+                auto_reset=fused_reset, refill_every=self._prefetch_delay, donate=self._donate,
+                aggregate=self._aggregate)
         return sess
 
     # ---------------------------------------------------------------------------------- reset
@@ -130,7 +135,7 @@ class Connector:
         else:
             st = _state_bufs(self._generator(keys), True)
             ts = ops.connector_observe(st)
-        return _make_state(st, batched), _make_timestep(ts, batched)
+        return _make_state(st, batched), self._single_agent_view(_make_timestep(ts, batched))
 
     # ---------------------------------------------------------------------------------- step
     def step(self, state: State, action: torch.Tensor) -> Tuple[State, TimeStep]:
@@ -152,7 +157,14 @@ class Connector:
                                     self._reward_fn.connected_reward, auto_reset=fused_reset)
         if self._auto_reset and not fused_reset:
             so, ts = self._generic_auto_reset(so, ts)
-        return _make_state(so, batched), _make_timestep(ts, batched)
+        return _make_state(so, batched), self._single_agent_view(_make_timestep(ts, batched))
+
+    def _single_agent_view(self, ts: TimeStep) -> TimeStep:
+        """MultiToSingleWrapper on the paths without a fused aggregate (single envs, generators
+        other than ParallelRandomWalk under auto-reset)."""
+        if not self._aggregate:
+            return ts
+        return ts._replace(reward=ts.reward.sum(dim=-1), discount=ts.discount.max(dim=-1).values)
 
     # ---------------------------------------------------------------------------------- rollout
     def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,

@@ -2,7 +2,7 @@
 routing_board_generation/rl_training/setup_train.py:158-167.
 
 The native env is already batched, so VmapAutoResetWrapper only switches on the fused auto-reset
-of `rbg_connector_step`; MultiToSingleWrapper aggregates per-agent reward (sum) and discount (max).
+of `rbg_connector_step`, and MultiToSingleWrapper the fused per-env reward sum / discount max.
 """
 from typing import Tuple
 
@@ -24,16 +24,19 @@ class _Wrapper:
 
 
 class MultiToSingleWrapper(_Wrapper):
-    def _aggregate(self, ts: TimeStep) -> TimeStep:
-        return ts._replace(reward=ts.reward.sum(dim=-1), discount=ts.discount.max(dim=-1).values)
+    """reward = sum over agents, discount = max over agents ([3P] jumanji.wrappers).  The native
+    Connector aggregates inside its step launch (rbg_timestep.reward_total / discount_max), so
+    this wrapper only switches that on."""
+
+    def __init__(self, env):
+        super().__init__(env)
+        env.unwrapped._aggregate = True
 
     def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
-        state, ts = self._env.reset(key)
-        return state, self._aggregate(ts)
+        return self._env.reset(key)
 
     def step(self, state: State, action: torch.Tensor) -> Tuple[State, TimeStep]:
-        state, ts = self._env.step(state, action)
-        return state, self._aggregate(ts)
+        return self._env.step(state, action)
 
 
 class VmapAutoResetWrapper(_Wrapper):

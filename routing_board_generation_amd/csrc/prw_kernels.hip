@@ -577,7 +577,8 @@ StatePtrs to_ptrs(const rbg_state *s) {
 TimestepPtrs to_ptrs(const rbg_timestep *t) {
   TimestepPtrs p = {t->step_type,      t->reward,          t->discount,
                     t->obs_grid,       t->action_mask,     t->obs_step_count,
-                    t->num_connections, t->ratio_connections, t->total_path_length};
+                    t->num_connections, t->ratio_connections, t->total_path_length,
+                    t->reward_total,   t->discount_max};
   return p;
 }
 bool state_complete(const rbg_state *s) {

@@ -111,6 +111,8 @@ struct TimestepPtrs {
   int32_t *num_connections;
   float *ratio_connections;
   int32_t *total_path_length;
+  float *reward_total;
+  float *discount_max;
 };
 struct StatePtrs {
   int32_t *grid;
@@ -281,16 +283,32 @@ __device__ __forceinline__ void write_restart(int N, int b, int lane, const Time
     if (ts.reward) ts.reward[(size_t)b * N + lane] = 0.0f;
     if (ts.discount) ts.discount[(size_t)b * N + lane] = 1.0f;
   }
-  if (lane == 0 && ts.step_type) ts.step_type[b] = 0;
+  if (lane == 0) {
+    if (ts.step_type) ts.step_type[b] = 0;
+    if (ts.reward_total) ts.reward_total[b] = 0.0f;
+    if (ts.discount_max) ts.discount_max[b] = 1.0f;
+  }
 }
 
 // reward/discount/step_type of a stepped timestep
 __device__ __forceinline__ void write_step_outcome(const StepResult &res, const rbg_env_params &p,
                                                    int N, int b, int lane,
                                                    const TimestepPtrs &ts) {
+  const float reward = dense_reward(res, p);
+  const bool alive = !(res.last || res.done);
   if (lane < N) {
-    if (ts.reward) ts.reward[(size_t)b * N + lane] = dense_reward(res, p);
-    if (ts.discount) ts.discount[(size_t)b * N + lane] = (res.last || res.done) ? 0.0f : 1.0f;
+    if (ts.reward) ts.reward[(size_t)b * N + lane] = reward;
+    if (ts.discount) ts.discount[(size_t)b * N + lane] = alive ? 1.0f : 0.0f;
+  }
+  if (ts.reward_total) {  // MultiToSingleWrapper: float32 sum in agent order (wave-uniform branch)
+    float total = 0.0f;
+    for (int i = 0; i < N; ++i)
+      total = __fadd_rn(total, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(reward), i)));
+    if (lane == 0) ts.reward_total[b] = total;
+  }
+  if (ts.discount_max) {
+    const bool any_alive = __ballot(lane < N && alive) != 0ull;
+    if (lane == 0) ts.discount_max[b] = any_alive ? 1.0f : 0.0f;
   }
   if (lane == 0 && ts.step_type) ts.step_type[b] = res.last ? 2 : 1;
 }

@@ -15,7 +15,8 @@ TimestepBufs = Dict[str, torch.Tensor]
 
 STATE_FIELDS = ("grid", "step_count", "start", "target", "position", "key")
 TIMESTEP_FIELDS = ("step_type", "reward", "discount", "obs_grid", "action_mask",
-                   "obs_step_count", "num_connections", "ratio_connections", "total_path_length")
+                   "obs_step_count", "num_connections", "ratio_connections", "total_path_length",
+                   "reward_total", "discount_max")
 
 
 def _stream(device: torch.device) -> C.c_void_p:
@@ -61,7 +62,10 @@ def alloc_state(B: int, m: int, N: int, device) -> StateBufs:
     }
 
 
-def alloc_timestep(B: int, m: int, N: int, device, with_obs_grid: bool = True) -> TimestepBufs:
+def alloc_timestep(B: int, m: int, N: int, device, with_obs_grid: bool = True,
+                   aggregate: bool = False) -> TimestepBufs:
+    """aggregate=True: reward_total / discount_max [B] (MultiToSingleWrapper inside the launch)
+    instead of the per-agent reward / discount [B, N]."""
     ts = {
         "step_type": torch.empty((B,), dtype=torch.int8, device=device),
         "reward": torch.empty((B, N), dtype=torch.float32, device=device),
@@ -74,6 +78,10 @@ def alloc_timestep(B: int, m: int, N: int, device, with_obs_grid: bool = True) -
     }
     if with_obs_grid:
         ts["obs_grid"] = torch.empty((B, N, m, m), dtype=torch.int32, device=device)
+    if aggregate:
+        del ts["reward"], ts["discount"]
+        ts["reward_total"] = torch.empty((B,), dtype=torch.float32, device=device)
+        ts["discount_max"] = torch.empty((B,), dtype=torch.float32, device=device)
     return ts
 
 
@@ -93,6 +101,7 @@ def _timestep_struct(ts: TimestepBufs, B: int, m: int, N: int) -> nat.Timestep:
         "action_mask": (torch.bool, (B, N, 5)), "obs_step_count": (torch.int32, (B,)),
         "num_connections": (torch.int32, (B,)), "ratio_connections": (torch.float32, (B,)),
         "total_path_length": (torch.int32, (B,)),
+        "reward_total": (torch.float32, (B,)), "discount_max": (torch.float32, (B,)),
     }
     ptrs = []
     for f in TIMESTEP_FIELDS:
@@ -537,9 +546,12 @@ class ConnectorSession:
 
     def __init__(self, B: int, m: int, N: int, device, time_limit: int = 50,
                  timestep_reward: float = -0.03, connected_reward: float = 0.1,
-                 auto_reset: bool = False, refill_every: int = 0, donate: bool = False) -> None:
+                 auto_reset: bool = False, refill_every: int = 0, donate: bool = False,
+                 aggregate: bool = False) -> None:
+        """aggregate=True: the timestep carries reward_total / discount_max [B]
+        (MultiToSingleWrapper inside the launch) instead of per-agent reward / discount."""
         self.B, self.m, self.N, self.device = B, m, N, device
-        self.donate = bool(donate)
+        self.donate, self.aggregate = bool(donate), bool(aggregate)
         self._ring, self._ring_i = None, 0
         self._lib = nat.lib()
         self._p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
@@ -556,10 +568,14 @@ class ConnectorSession:
         self._specs = (
             ("grid", i32, (B, m, m)), ("step_count", i32, (B,)), ("start", i32, (B, N, 2)),
             ("target", i32, (B, N, 2)), ("position", i32, (B, N, 2)), ("key", torch.uint32, (B, 2)),
-            ("step_type", torch.int8, (B,)), ("reward", f32, (B, N)), ("discount", f32, (B, N)),
+            ("step_type", torch.int8, (B,)),
+            ("reward", None if aggregate else f32, (B, N)),
+            ("discount", None if aggregate else f32, (B, N)),
             ("obs_grid", i32, (B, N, m, m)), ("action_mask", torch.bool, (B, N, 5)),
             ("obs_step_count", i32, (B,)), ("num_connections", i32, (B,)),
-            ("ratio_connections", f32, (B,)), ("total_path_length", i32, (B,)))
+            ("ratio_connections", f32, (B,)), ("total_path_length", i32, (B,)),
+            ("reward_total", f32 if aggregate else None, (B,)),
+            ("discount_max", f32 if aggregate else None, (B,)))  # dtype None: output not wanted
         self.chunk_steps = max(1, min(16, (256 << 20) // (4 * B * N * m * m)))
         self._views, self._bases, self._cursor = None, None, 0
 
@@ -569,9 +585,12 @@ class ConnectorSession:
         i = self._cursor
         if self._views is None or i == self.chunk_steps:
             S, dev = self.chunk_steps, self.device
-            chunks = [torch.empty((S,) + shape, dtype=dt, device=dev) for _, dt, shape in self._specs]
-            self._views = list(zip(*[c.unbind(0) for c in chunks]))  # [step][field]
-            self._bases = [(c.data_ptr(), c[0].numel() * c.element_size()) for c in chunks]
+            chunks = [None if dt is None else torch.empty((S,) + shape, dtype=dt, device=dev)
+                      for _, dt, shape in self._specs]
+            self._views = list(zip(*[(None,) * S if c is None else c.unbind(0)
+                                     for c in chunks]))  # [step][field]
+            self._bases = [(0, 0) if c is None else (c.data_ptr(), c[0].numel() * c.element_size())
+                           for c in chunks]  # absent field: pointer 0 = NULL
             i = 0
         self._cursor = i + 1
         v = self._views[i]
@@ -585,9 +604,9 @@ class ConnectorSession:
         if self._ring is None:
             self._ring = []
             for _ in range(2):
-                ts = alloc_timestep(self.B, self.m, self.N, self.device)
-                v = tuple(ts[f] for f in TIMESTEP_FIELDS)
-                self._ring.append((v, nat.Timestep(*[x.data_ptr() for x in v])))
+                ts = alloc_timestep(self.B, self.m, self.N, self.device, aggregate=self.aggregate)
+                v = tuple(ts.get(f) for f in TIMESTEP_FIELDS)
+                self._ring.append((v, nat.Timestep(*[_ptr(x) for x in v])))
         self._ring_i ^= 1
         tv, t = self._ring[self._ring_i]
         if in_leaves is None:  # reset

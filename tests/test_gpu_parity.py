@@ -710,3 +710,40 @@ def test_donated_stepping_matches_oracle(rbg, oracle, prefetch):
         prev_ts, prev_ets = ts, {k: np.copy(v) for k, v in ets.items()}
     for sess in env.unwrapped._sessions.values():
         sess.drain()
+
+
+@pytest.mark.parametrize("donate,prefetch", [(False, False), (True, True)])
+def test_multi_to_single_aggregates_inside_the_launch(rbg, oracle, donate, prefetch):
+    """The reference's training env, VmapAutoResetWrapper(MultiToSingleWrapper(Connector))
+    (setup_train.py:158-167): reward summed over agents in float32 agent order, discount = max,
+    produced by the step launch itself (rbg_timestep.reward_total / discount_max)."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, steps, tl = 16, 10, 300, 60, 14
+    env = rbg.VmapAutoResetWrapper(rbg.MultiToSingleWrapper(
+        rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), time_limit=tl,
+                      donate=donate)), prefetch=prefetch, prefetch_delay=3)
+    keys, akeys = _keys(rbg, 101, B), _keys(rbg, 102, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle.connector_reset_batch(to_np(keys), m, N, threads=8)
+    assert ts.reward.shape == (B,) and ts.discount.shape == (B,)
+    assert (to_np(ts.reward) == 0).all() and (to_np(ts.discount) == 1).all()
+    seen_nonzero = 0
+    for t in range(steps):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        state, ts = env.step(state, action)
+        ets = oracle.connector_step_batch(est, eaction, time_limit=tl, auto_reset=True, threads=8)
+        total = np.zeros((B,), dtype=np.float32)
+        for i in range(N):  # ((0 + r_0) + r_1) + ... in float32
+            total = (total + ets["reward"][:, i]).astype(np.float32)
+        assert (to_np(ts.reward).view(np.uint32) == total.view(np.uint32)).all(), t
+        assert (to_np(ts.discount) == ets["discount"].max(axis=1)).all(), t
+        assert np.allclose(to_np(ts.reward), ets["reward"].sum(axis=1), atol=1e-6)
+        assert (to_np(ts.step_type) == ets["step_type"]).all()
+        assert (to_np(ts.observation.grid) == ets["obs_grid"]).all()
+        assert_dicts_equal(state_to_np(state), est, f"step {t} state.")
+        seen_nonzero += int((total != 0).sum())
+    assert seen_nonzero > B
+    for sess in env.unwrapped._sessions.values():
+        sess.drain()

@@ -40,7 +40,7 @@ def test_version_and_abi(native):
 
 def test_struct_layouts_match_header(native):
     assert C.sizeof(native.State) == 6 * C.sizeof(C.c_void_p)
-    assert C.sizeof(native.Timestep) == 9 * C.sizeof(C.c_void_p)
+    assert C.sizeof(native.Timestep) == 11 * C.sizeof(C.c_void_p)
     assert C.sizeof(native.EnvParams) == 16
 
 
