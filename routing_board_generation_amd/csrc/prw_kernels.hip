@@ -61,6 +61,9 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int first = (blockIdx.x * kWavesPerBlock + wib) * kSubs;
   if (first >= a.B) return;  // wave-uniform; waves of a block never synchronise with each other
+#if defined(RBG_PROBE_TIMES)  // developer probe (tools/probe_walk.py --times): wave start / end
+  const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
 #if defined(RBG_PROBE_STAGE) && RBG_PROBE_STAGE == 0
   return;
 #endif
@@ -80,6 +83,11 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   }
 
   Walker w;
+#if defined(RBG_PROBE_TIMES)  // stamps go to the solved_grid buffer (8 per wave); no solved grid
+  w.stamp = a.solved_grid + (size_t)(blockIdx.x * kWavesPerBlock + wib) * 8;
+  if (sw.lane == 0) w.stamp[0] = (int32_t)probe_t0;
+  RBG_STAMP(w, 1);
+#endif
   if constexpr (LPB == kWaveSize) {
     prw_walk_full(sw, board, W, g, a.N, key, w);
   } else {
@@ -88,7 +96,9 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   if (!valid) return;
 
   const size_t gofs = (size_t)b * g.n;
+#if !defined(RBG_PROBE_TIMES)
   if (a.solved_grid) store_grid<LPB, false>(board, g, sw.l, a.solved_grid + gofs);
+#endif
   if (a.train_grid) store_grid<LPB, true>(board, g, sw.l, a.train_grid + gofs);
   if (sw.l < a.N) {
     const size_t o = ((size_t)b * a.N + sw.l) * 2;
@@ -99,7 +109,19 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   if (sw.l == 0) {
     if (a.key_out) *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(key.a, key.b);
     if (a.step_count) a.step_count[b] = 0;
+#if defined(RBG_PROBE_HWID)  // developer probe (tools/probe_walk.py --placement): where the wave ran
+    if (a.iters)
+      a.iters[b] = (int)(((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 16) |
+                         (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu));
+#elif defined(RBG_PROBE_TIMES)
     if (a.iters) a.iters[b] = w.iters;
+    if (a.step_count)  // where the wave ran: XCC_ID << 16 | HW_ID[15:0]
+      a.step_count[b] = (int)(((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 16) |
+                              (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu));
+    RBG_STAMP(w, 7);
+#else
+    if (a.iters) a.iters[b] = w.iters;
+#endif
   }
 }
 

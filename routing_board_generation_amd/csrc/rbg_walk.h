@@ -15,11 +15,18 @@ namespace rbg {
 //   fast path  a threshold `thr` (host-computed so that a few times `count` keys fall below it)
 //              filters the candidates, a ballot/popcount prefix compacts them into LDS, and
 //              every lane ranks its candidate against the others (LDS broadcast reads) -- exact
-//              whenever count <= #candidates <= LPB;
-//   slow path  otherwise (rare, or thr == 0): `count` sub-wave-wide 64-bit min-reductions.
+//              whenever count <= #candidates <= LPB.  A board with too few (too many)
+//              candidates moves its threshold (x1.5 / x0.625, then bisection) and tries again,
+//              three times at most: a miss costs one more compaction, not the slow path (0.5 %
+//              of the boards miss once at 16x16 / 10 agents / 32 lanes).  Up to kKeyRounds * LPB Threefry blocks the sort
+//              keys never leave the registers.
+//   slow path  otherwise (thr == 0, or four misses): `count` sub-wave-wide 64-bit
+//              min-reductions over the keys in `scratch`.
 // Sub-lane l receives entry l in sel0 and entry LPB + l in sel1.
 // `scratch` needs n words (the board area is used), `aux` 2*LPB words.
 // ---------------------------------------------------------------------------------------------
+constexpr int kKeyRounds = 4;  // register-resident sort keys: 2 * kKeyRounds words per lane
+
 template <int LPB>
 __device__ __forceinline__ void shuffle_prefix(const SubWave<LPB> &sw, uint32_t *scratch,
                                                uint32_t *aux, const Geo &g, Key2 sub, int count,
@@ -27,50 +34,117 @@ __device__ __forceinline__ void shuffle_prefix(const SubWave<LPB> &sw, uint32_t 
   const uint32_t n = (uint32_t)g.n;
   const uint32_t half = (n + 1u) >> 1;
   const int l = sw.l;
-  for (uint32_t j = l; j < half; j += LPB) {
-    const bool has_hi = half + j < n;
-    const uint2 y = threefry_call(sub.a, sub.b, j, has_hi ? half + j : 0u);
-    scratch[j] = y.x;
-    if (has_hi) scratch[half + j] = y.y;
-  }
-  wave_lds_fence();
   sel0 = sel1 = -1;
+  // Threefry block j yields the keys of cells j (y0) and half + j (y1)
+  const bool in_regs = thr != 0u && half <= (uint32_t)(kKeyRounds * LPB);  // wave-uniform
+  uint32_t klo[kKeyRounds], khi[kKeyRounds];
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kKeyRounds; ++k) {
+      klo[k] = khi[k] = 0u;
+      if ((uint32_t)(k * LPB) < half) {
+        const uint32_t j = (uint32_t)(l + k * LPB);
+        const uint2 y = threefry_call(sub.a, sub.b, j < half ? j : 0u, half + j < n ? half + j : 0u);
+        klo[k] = y.x;
+        khi[k] = y.y;
+      }
+    }
+  } else {
+    for (uint32_t j = l; j < half; j += LPB) {
+      const bool has_hi = half + j < n;
+      const uint2 y = threefry_call(sub.a, sub.b, j, has_hi ? half + j : 0u);
+      scratch[j] = y.x;
+      if (has_hi) scratch[half + j] = y.y;
+    }
+    wave_lds_fence();
+  }
 
   bool ok = false;
   if (thr != 0u) {
-    // ---- compact the candidates (key < thr), in index order, as (key, index) pairs ----------
     const uint64_t lt_mask = (1ull << l) - 1ull;
-    int total = 0;
-    for (uint32_t base = 0; base < n; base += LPB) {
-      const uint32_t j = base + l;
-      const uint32_t key = j < n ? scratch[j] : 0xFFFFFFFFu;
-      const bool flag = j < n && key < thr;
-      const uint64_t mask = sw.ballot(flag);
-      const int pos = total + __popcll(mask & lt_mask);
-      if (flag && pos < LPB) *reinterpret_cast<uint2 *>(&aux[2 * pos]) = make_uint2(key, j);
-      total += __popcll(mask);
+    uint32_t thr_cur = thr;                   // per board
+    uint32_t thr_few = 0u, thr_many = 0u;     // thresholds known to give too few / too many
+#pragma unroll 1
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      // ---- compact the candidates (key < thr_cur) as (key, index) pairs ----------------------
+      int total = 0;
+      auto emit = [&](bool flag, uint32_t key, uint32_t idx) {
+        const uint64_t mask = sw.ballot(flag);
+        const int pos = total + __popcll(mask & lt_mask);
+        if (flag && pos < LPB) *reinterpret_cast<uint2 *>(&aux[2 * pos]) = make_uint2(key, idx);
+        total += __popcll(mask);
+      };
+      if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kKeyRounds; ++k) {
+          if ((uint32_t)(k * LPB) < half) {
+            const uint32_t j = (uint32_t)(l + k * LPB);
+            emit(j < half && klo[k] < thr_cur, klo[k], j);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kKeyRounds; ++k) {
+          if ((uint32_t)(k * LPB) < half) {
+            const uint32_t j = (uint32_t)(l + k * LPB);
+            emit(j < half && half + j < n && khi[k] < thr_cur, khi[k], half + j);
+          }
+        }
+      } else {
+        for (uint32_t base = 0; base < n; base += LPB) {
+          const uint32_t j = base + l;
+          const uint32_t key = j < n ? scratch[j] : 0xFFFFFFFFu;
+          emit(j < n && key < thr_cur, key, j);
+        }
+      }
+      // unused slots compare greater than every candidate: the rank loop needs no bounds test
+      if (l >= total) *reinterpret_cast<uint2 *>(&aux[2 * l]) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      wave_lds_fence();
+      const bool fits = total >= count && total <= LPB;
+      // ---- rank every candidate among the candidates of its board ----------------------------
+      const int bound = min(sw.max_over_subs(total), LPB);
+      const uint2 mine_kv = *reinterpret_cast<const uint2 *>(&aux[2 * l]);
+      const uint64_t mine = ((uint64_t)mine_kv.x << 32) | mine_kv.y;
+      int rank = 0;
+      for (int c = 0; c < bound; c += 2) {  // two pairs per broadcast read (LPB is even)
+        const uint4 o = *reinterpret_cast<const uint4 *>(&aux[2 * c]);
+        rank += (int)((((uint64_t)o.x << 32) | o.y) < mine);
+        rank += (int)((((uint64_t)o.z << 32) | o.w) < mine);
+      }
+      wave_lds_fence();
+      const bool take = fits && !ok;
+      if (take && l < total) aux[rank] = mine_kv.y;  // ranks of distinct pairs form a permutation
+      wave_lds_fence();
+      if (take && l < count) sel0 = (int)aux[l];
+      wave_lds_fence();
+      ok = ok || fits;
+      if (__ballot(!ok) == 0ull) return;
+      if (!ok) {  // x1.5 / x0.625 towards the expected count, bisection once both sides are known
+        if (total < count) {
+          thr_few = thr_cur;
+          const uint64_t up = (uint64_t)thr_cur + (thr_cur >> 1);
+          thr_cur = thr_many ? thr_few + ((thr_many - thr_few) >> 1)
+                             : (up > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)up);
+        } else {
+          thr_many = thr_cur;
+          thr_cur = thr_few ? thr_few + ((thr_many - thr_few) >> 1)
+                            : (thr_cur >> 1) + (thr_cur >> 3);
+        }
+      }
     }
-    wave_lds_fence();
-    ok = total >= count && total <= LPB;
-    // ---- rank every candidate among the candidates of its board -----------------------------
-    const int bound = min(sw.max_over_subs(total), LPB);
-    uint2 mine_kv = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (l < total && total <= LPB) mine_kv = *reinterpret_cast<const uint2 *>(&aux[2 * l]);
-    const uint64_t mine = ((uint64_t)mine_kv.x << 32) | mine_kv.y;
-    int rank = 0;
-    for (int c = 0; c < bound; ++c) {
-      const uint2 o = *reinterpret_cast<const uint2 *>(&aux[2 * c]);  // broadcast inside the board
-      rank += (int)(c < total && (((uint64_t)o.x << 32) | o.y) < mine);
-    }
-    wave_lds_fence();
-    if (ok && l < total) aux[rank] = mine_kv.y;  // ranks of distinct pairs form a permutation
-    wave_lds_fence();
-    if (ok && l < count) sel0 = (int)aux[l];
-    wave_lds_fence();
   }
-  if (__ballot(!ok) == 0ull) return;
 
   // ---- slow path (boards with ok == false): one 64-bit min-reduction per entry ---------------
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kKeyRounds; ++k) {
+      const uint32_t j = (uint32_t)(l + k * LPB);
+      if (j < half) {
+        scratch[j] = klo[k];
+        if (half + j < n) scratch[half + j] = khi[k];
+      }
+    }
+    wave_lds_fence();
+  }
   uint64_t prev = 0;
   bool have_prev = false;
   for (int round = 0; round < count; ++round) {
@@ -205,7 +279,21 @@ struct Walker {
   int r, c;    // current head (row, col)
   int P;       // padded index of the head
   int iters;   // while_loop trip count of this lane's board
+#if defined(RBG_PROBE_TIMES)
+  int32_t *stamp;  // developer probe (tools/probe_walk.py --times): 8 s_memtime stamps per wave
+#endif
 };
+
+#if defined(RBG_PROBE_TIMES)
+#define RBG_STAMP(w, i)                                                     \
+  do {                                                                      \
+    if ((threadIdx.x & 63) == 0) (w).stamp[i] = (int32_t)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define RBG_STAMP(w, i) \
+  do {                  \
+  } while (0)
+#endif
 
 // Runs generate_board(key) for the board of this lane's sub-wave on `board` (LDS, padded) with
 // scratch `W`.  On return the board holds the solved grid with the head/target encodings of
@@ -229,8 +317,10 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
   // _initialise_agents (:147-186): N distinct cells = first N of the shuffled arange(m*m);
   // _shuffle's round does key, sub = split(key) first
   split2_lanes(sw, kB, unused, sub);
+  RBG_STAMP(w, 2);
   int sel0, sel1;
   shuffle_prefix(sw, board, W, g, sub, N, g.thr, sel0, sel1);
+  RBG_STAMP(w, 3);
   w.iters = 0;
 #if defined(RBG_PROBE_STAGE) && RBG_PROBE_STAGE == 1  // developer probe: stop after the shuffle
   w.r0 = w.c0 = w.r = w.c = sel0;
@@ -250,6 +340,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     board[w.P] = wire;
   }
   wave_lds_fence();
+  RBG_STAMP(w, 4);
 #if defined(RBG_PROBE_STAGE) && RBG_PROBE_STAGE == 2  // developer probe: stop before the prologue
   return;
 #endif
@@ -265,6 +356,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     u = prng_round_multi(W, N, sw.lane, kcur);
   }
 
+  RBG_STAMP(w, 5);
   const int S = g.S;
   const int idle_word = l % (2 * S);  // the first two padded rows are walls
   // Every iteration that runs moves at least the highest-id mover of a live board into an empty
@@ -351,6 +443,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     wave_lds_fence();
     u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
   }
+  RBG_STAMP(w, 6);
 
   unpad_index(g, w.P, w.r, w.c);  // the loop tracks the padded index only
   // update_solved_board_with_head_target_encodings (:435-447): heads first, then targets

@@ -63,6 +63,12 @@ def main():
     ap.add_argument("--stages", type=str, default="",
                     help="probe builds that stop early: 0 empty kernel, 1 after the shuffle, "
                          "2 after board_clear (all with cap 0)")
+    ap.add_argument("--placement", action="store_true",
+                    help="probe build that reports where each wave ran (HW_ID / XCC_ID): waves "
+                         "per SIMD for one launch of 4096 boards")
+    ap.add_argument("--times", action="store_true",
+                    help="probe build that records every wave's start and end time (s_memtime): "
+                         "start delay and duration by block index for one launch of 4096 boards")
     ap.add_argument("--batches", type=str, default="64,256,1024,2048,4096,8192,16384,65536")
     args = ap.parse_args()
     print(f"# {args.m}x{args.m}/{args.n}: kernel time (us, p50) vs batch")
@@ -79,6 +85,98 @@ def main():
             us, mean_it, max_it = time_generate(B, args.m, args.n, lib=lib)
             print(f"cap={cap:4d} B={B:5d}  {us:9.1f} us  (iters mean {mean_it:.1f} max {max_it})")
     probe_stages(args)
+    if args.placement:
+        probe_placement(args)
+    if args.times:
+        probe_times(args)
+
+
+def probe_times(args):
+    """Per-wave timeline of one C2-shaped launch: 8 s_memtime stamps per wave (entry, keys,
+    before / after the start-cell shuffle, board ready, loop start, loop end, outputs stored).
+    s_memtime is per XCD, so times are taken relative to the first wave of the same XCD."""
+    import numpy as np
+
+    so = os.path.join(ROOT, "gpurun_out", "librbg_probe_times.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                          ["-DRBG_PROBE_TIMES", "-o", so, nat.SRC_PATH])
+    lib = C.CDLL(so)
+    B = 4096
+    keys = rbg.split(rbg.PRNGKey(0), B)
+    out = ops.prw_generate(keys, args.m, args.n, split_first=True, want_solved=True,
+                           want_state=True, want_iters=True)
+    for rep in range(3):
+        rc = lib.rbg_prw_generate(
+            C.c_void_p(keys.data_ptr()), B, args.m, args.n, 1,
+            C.c_void_p(out["solved_grid"].data_ptr()),
+            C.c_void_p(out["train_grid"].data_ptr()), C.c_void_p(out["start"].data_ptr()),
+            C.c_void_p(out["target"].data_ptr()), C.c_void_p(out["position"].data_ptr()),
+            C.c_void_p(out["step_count"].data_ptr()), C.c_void_p(out["key_out"].data_ptr()),
+            C.c_void_p(out["iters"].data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+    n_waves = B // 2
+    T = out["iters"].cpu().numpy().reshape(-1, 2).max(axis=1)
+    st = out["solved_grid"].cpu().numpy().reshape(-1)[:n_waves * 8].astype(np.uint32).reshape(-1, 8)
+    hw = out["step_count"].cpu().numpy().reshape(-1, 2)[:, 0]
+    xcd = hw >> 16
+    rel = np.zeros((n_waves, 8), np.int64)
+    for x in np.unique(xcd):
+        sel = xcd == x
+        rel[sel] = (st[sel] - st[sel, 0].min()).astype(np.uint32)
+    block = np.arange(n_waves) // 4
+    second = block >= block.max() // 2 + 1
+    names = ["entry", "keys", "pre-shuffle", "shuffle", "board", "pipeline", "loop", "stored"]
+    print(f"kernel span per XCD (shader cycles): {[int(rel[xcd == x, 7].max()) for x in np.unique(xcd)]}")
+    for label, sel in (("first half of the blocks", ~second), ("second half of the blocks", second)):
+        seg = np.diff(rel[sel], axis=1).mean(axis=0)
+        print(f"{label}: entry at {rel[sel, 0].mean():7.0f} (max {rel[sel, 0].max()}); segments "
+              + ", ".join(f"{n} {v:6.0f}" for n, v in zip(names[1:], seg))
+              + f"; loop/T {((rel[sel, 6] - rel[sel, 5]) / np.maximum(T[sel], 1)).mean():6.0f}")
+    for w in np.argsort(rel[:, 7])[-6:][::-1]:
+        print(f"late finisher: wave {w} (block {block[w]}, xcd {xcd[w]}) T {T[w]}: "
+              + " ".join(f"{n} {v}" for n, v in zip(names, rel[w])))
+    w = int(np.argmax(T))
+    print(f"longest board: wave {w} (block {block[w]}) T {T[w]}: "
+          + " ".join(f"{n} {v}" for n, v in zip(names, rel[w])))
+
+
+def probe_placement(args):
+    import collections
+
+    so = os.path.join(ROOT, "gpurun_out", "librbg_probe_hwid.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                          ["-DRBG_PROBE_HWID", "-o", so, nat.SRC_PATH])
+    lib = C.CDLL(so)
+    B = 4096
+    keys = rbg.split(rbg.PRNGKey(0), B)
+    out = ops.prw_generate(keys, args.m, args.n, split_first=True, want_solved=False,
+                           want_state=True, want_iters=True)
+    for rep in range(3):
+        rc = lib.rbg_prw_generate(
+            C.c_void_p(keys.data_ptr()), B, args.m, args.n, 1, None,
+            C.c_void_p(out["train_grid"].data_ptr()), C.c_void_p(out["start"].data_ptr()),
+            C.c_void_p(out["target"].data_ptr()), C.c_void_p(out["position"].data_ptr()),
+            C.c_void_p(out["step_count"].data_ptr()), C.c_void_p(out["key_out"].data_ptr()),
+            C.c_void_p(out["iters"].data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        ids = out["iters"].cpu().tolist()
+        # one entry per board; boards of one wave report the same place: count waves
+        per_simd = collections.Counter()
+        per_cu = collections.Counter()
+        seen = set()
+        lpb_boards = 2 if 2 * args.n + 2 <= 32 else 1
+        for b in range(0, B, lpb_boards):
+            v = ids[b]
+            xcc, se, sh, cu, simd = v >> 16, (v >> 13) & 7, (v >> 12) & 1, (v >> 8) & 15, (v >> 4) & 3
+            per_simd[(xcc, se, sh, cu, simd)] += 1
+            per_cu[(xcc, se, sh, cu)] += 1
+        print(f"launch {rep}: {len(per_cu)} CUs, {len(per_simd)} SIMDs used; waves per SIMD histogram "
+              f"{sorted(collections.Counter(per_simd.values()).items())}; waves per CU histogram "
+              f"{sorted(collections.Counter(per_cu.values()).items())}")
 
 
 def probe_stages(args):
