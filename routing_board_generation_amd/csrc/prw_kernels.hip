@@ -376,7 +376,8 @@ struct RolloutArgs {
   int tick, ready_delay;
 };
 
-__global__ __launch_bounds__(kBlock) void connector_rollout_kernel(RolloutArgs a) {
+// (4 waves per SIMD = one launch of 4096 envs resident at once: keep the VGPR budget at 128)
+__global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;

@@ -236,6 +236,19 @@ __device__ __forceinline__ int slab_words(const Geo &g) {  // one board + its sc
 // walls everywhere, zeros inside
 template <int LPB>
 __device__ __forceinline__ void board_clear(uint32_t *board, const Geo &g, int l) {
+  if ((g.m & 3) == 0) {
+    // S = m + 4 and words = S * S are multiples of 4 and rows start 16-byte aligned: 128-bit stores
+    const uint4 wall = make_uint4(kWall, kWall, kWall, kWall), zero = make_uint4(0u, 0u, 0u, 0u);
+    for (int w = l * 4; w < g.words; w += LPB * 4) *reinterpret_cast<uint4 *>(&board[w]) = wall;
+    wave_lds_fence();
+    const int per_row = g.m >> 2;  // 4-cell groups per row
+    for (int q = l; q < per_row * g.m; q += LPB) {
+      const int r = div_m(g, q * 4);
+      *reinterpret_cast<uint4 *>(&board[pad_index(g, r, (q - r * per_row) * 4)]) = zero;
+    }
+    wave_lds_fence();
+    return;
+  }
   for (int w = l; w < g.words; w += LPB) board[w] = kWall;
   wave_lds_fence();
   for (int idx = l; idx < g.n; idx += LPB) {

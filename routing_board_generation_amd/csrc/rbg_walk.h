@@ -101,11 +101,12 @@ __device__ __forceinline__ void shuffle_prefix(const SubWave<LPB> &sw, uint32_t 
       wave_lds_fence();
       const bool fits = total >= count && total <= LPB;
       // ---- rank every candidate among the candidates of its board ----------------------------
-      const int bound = min(sw.max_over_subs(total), LPB);
+      // (all LPB slots hold a pair or the filler; two broadcast reads in flight: more costs the rollout kernel its 4th wave)
       const uint2 mine_kv = *reinterpret_cast<const uint2 *>(&aux[2 * l]);
       const uint64_t mine = ((uint64_t)mine_kv.x << 32) | mine_kv.y;
       int rank = 0;
-      for (int c = 0; c < bound; c += 2) {  // two pairs per broadcast read (LPB is even)
+#pragma unroll 2
+      for (int c = 0; c < LPB; c += 2) {  // two pairs per read
         const uint4 o = *reinterpret_cast<const uint4 *>(&aux[2 * c]);
         rank += (int)((((uint64_t)o.x << 32) | o.y) < mine);
         rank += (int)((((uint64_t)o.z << 32) | o.w) < mine);
