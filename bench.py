@@ -55,8 +55,7 @@ def measured_traffic(kernel: str, boards: int):
     Only valid for the launch shape it was measured on (B = 4096, 16x16/10)."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")),
-                   key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))  # rNN tags
     if not files or boards != BATCH_PER_GPU:
         return None
     kernels = json.load(open(files[-1]))["kernels"]

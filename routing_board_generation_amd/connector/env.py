@@ -114,6 +114,8 @@ class Connector:
              self._reward_fn.timestep_reward, self._reward_fn.connected_reward)
         sess = self._sessions.get(k)
         if sess is None:
+            while len(self._sessions) >= 4:  # a session pins its current output chunk: keep few
+                self._sessions.pop(next(iter(self._sessions))).drain()
             sess = self._sessions[k] = ops.ConnectorSession(
                 B, self.grid_size, self.num_agents, device, self.time_limit,
                 self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
