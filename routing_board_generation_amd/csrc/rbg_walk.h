@@ -178,68 +178,71 @@ __device__ __forceinline__ void shuffle_prefix(const SubWave<LPB> &sw, uint32_t 
 // ---------------------------------------------------------------------------------------------
 template <int LPB>
 struct PrngLanes {  // per-lane constants of the single-evaluation layout (2N + 2 <= LPB)
-  bool r_uni, r_split;
+  bool r_uni;
   int w_read, w_y0, w_y1;  // LDS word indices into W
   uint32_t c0, c1;         // counters of this lane's role
-  int chain_lane;          // sub-lane of slot 2N
 };
 
+// W: words [0, 2N) = split(k, N) as y0-half ++ y1-half (key i = words 2i, 2i+1); words 2N, 2N+1 =
+// the chain key k that the split and chain slots of the NEXT evaluation start from.  Every lane
+// therefore finds the key of its role with one ds_read_b64 and nothing is broadcast through
+// readlanes.
 template <int LPB>
 __device__ __forceinline__ PrngLanes<LPB> prng_lanes(int N, int l) {
   PrngLanes<LPB> p;
   const int twoN = 2 * N, s = l, dump = 2 * LPB + 2 * l;  // this lane's own dump words
   p.r_uni = s < N;
-  p.r_split = !p.r_uni && s < twoN;
-  p.w_read = p.r_uni ? 2 * s : 0;
-  // out = y0-half ++ y1-half; the other roles park their stores in a dump slot (branch-free)
-  p.w_y0 = p.r_split ? s - N : dump;
-  p.w_y1 = p.r_split ? s : dump + 1;
+  const bool r_split = !p.r_uni && s < twoN;
+  const bool r_chain = s >= twoN && s < twoN + 2;
+  p.w_read = p.r_uni ? 2 * s : twoN;
+  // the other roles park their stores in a dump slot (branch-free); the chain slot x = s - 2N
+  // keeps y1 of block x, i.e. word x of split(k)[1], at W[2N + x] = W[s]
+  p.w_y0 = r_split ? s - N : dump;
+  p.w_y1 = (r_split || r_chain) ? s : dump + 1;
   // counters: uniform (0, pad 0) | split block j = s - N: (j, N + j) | split(k) block x: (x, x+2)
-  p.c0 = p.r_uni ? 0u : p.r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
-  p.c1 = p.r_uni ? 0u : p.r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
-  p.chain_lane = twoN;
+  p.c0 = p.r_uni ? 0u : r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
+  p.c1 = p.r_uni ? 0u : r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
   return p;
 }
 
 // The round cut in three pieces for software pipelining inside the walk loop:
-//   prng_issue   ds_read of this lane's uniform key (issued BEFORE the stencil reads so that
-//                waiting for it does not wait for them)
+//   prng_issue   ds_read of this lane's key (issued BEFORE the stencil reads so that waiting for
+//                it does not wait for them)
 //   prng_first   Threefry rounds 1-8   (runs under the stencil's LDS latency)
-//   prng_second  rounds 9-20, W stores, chain broadcast (runs under the move's ds_max + read-back)
+//   prng_second  rounds 9-20 and the W stores (run under the move's ds_max + read-back)
 template <int LPB>
 __device__ __forceinline__ uint2 prng_issue(const uint32_t *W, const PrngLanes<LPB> &p) {
-  // unconditional (index-clamped) load: a pointer select would become a flat load via scratch
   return *reinterpret_cast<const uint2 *>(&W[p.w_read]);
 }
 
 template <int LPB>
-__device__ __forceinline__ TfState prng_first(const PrngLanes<LPB> &p, uint2 kk, Key2 kcur) {
-  return threefry_first_half(p.r_uni ? kk.x : kcur.a, p.r_uni ? kk.y : kcur.b, p.c0, p.c1);
+__device__ __forceinline__ TfState prng_first(const PrngLanes<LPB> &p, uint2 kk) {
+  return threefry_first_half(kk.x, kk.y, p.c0, p.c1);
 }
 
 template <int LPB>
-__device__ __forceinline__ float prng_second(const SubWave<LPB> &sw, uint32_t *W,
-                                             const PrngLanes<LPB> &p, const TfState &t,
-                                             Key2 &kcur) {
+__device__ __forceinline__ float prng_second(uint32_t *W, const PrngLanes<LPB> &p,
+                                             const TfState &t) {
   uint32_t y0, y1;
   threefry_second_half(t, y0, y1);
   W[p.w_y0] = y0;
   W[p.w_y1] = y1;
-  kcur.a = sw.bcast(y1, p.chain_lane);
-  kcur.b = sw.bcast(y1, p.chain_lane + 1);
   return bits_to_uniform(y0);  // meaningful in the r_uni lanes
+}
+
+// Start of the pipeline: the chain key goes to its W slot.
+__device__ __forceinline__ void prng_seed(uint32_t *W, int N, int l, Key2 k) {
+  if (l == 0) *reinterpret_cast<uint2 *>(&W[2 * N]) = make_uint2(k.a, k.b);
+  wave_lds_fence();
 }
 
 // One whole round, out of the loop (pipeline prologue) -- single evaluation.
 template <int LPB>
-__device__ __forceinline__ float prng_round_single(const SubWave<LPB> &sw, uint32_t *W,
-                                                   const PrngLanes<LPB> &p, Key2 &kcur) {
+__device__ __forceinline__ float prng_round_single(uint32_t *W, const PrngLanes<LPB> &p) {
   const uint2 kk = prng_issue<LPB>(W, p);
-  const uint2 y = threefry_call(p.r_uni ? kk.x : kcur.a, p.r_uni ? kk.y : kcur.b, p.c0, p.c1);
+  const uint2 y = threefry_call(kk.x, kk.y, p.c0, p.c1);
   W[p.w_y0] = y.x;
   W[p.w_y1] = y.y;
-  kcur.a = sw.bcast(y.y, p.chain_lane);
-  kcur.b = sw.bcast(y.y, p.chain_lane + 1);
   wave_lds_fence();
   return bits_to_uniform(y.x);
 }
@@ -350,8 +353,9 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
   const PrngLanes<LPB> pl = prng_lanes<LPB>(N, l);
   float u;
   if (kSingle) {
-    (void)prng_round_single(sw, W, pl, kcur);
-    u = prng_round_single(sw, W, pl, kcur);
+    prng_seed(W, N, l, kcur);
+    (void)prng_round_single(W, pl);
+    u = prng_round_single(W, pl);
   } else {
     (void)prng_round_multi(W, N, sw.lane, kcur);
     u = prng_round_multi(W, N, sw.lane, kcur);
@@ -376,18 +380,20 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     // candidate q is available iff it is empty and touches no cell of this wire other than the
     // head itself ("doubling back" counts the head once, so the other three must be foreign).
     const int P = w.P;
-    const uint32_t vu = board[P - S], vd = board[P + S], vl = board[P - 1], vr = board[P + 1];
-    const uint32_t uu = board[P - 2 * S], dd = board[P + 2 * S];
-    const uint32_t ll = board[P - 2], rr = board[P + 2];
-    const uint32_t ul = board[P - S - 1], ur = board[P - S + 1];
-    const uint32_t dl = board[P + S - 1], dr = board[P + S + 1];
+    // five row pointers one stride apart; everything else is an immediate ds offset
+    const uint32_t *mid = board + P, *up = mid - S, *dn = mid + S, *up2 = up - S, *dn2 = dn + S;
+    const uint32_t vu = up[0], vd = dn[0], vl = mid[-1], vr = mid[1];
+    const uint32_t uu = up2[0], dd = dn2[0];
+    const uint32_t ll = mid[-2], rr = mid[2];
+    const uint32_t ul = up[-1], ur = up[1];
+    const uint32_t dl = dn[-1], dr = dn[1];
 
     // ... and the first Threefry rounds run while the stencil reads are in flight
     TfState tf = {0u, 0u, 0u, 0u, 0u};
     float u_next = 0.0f;
     __builtin_amdgcn_sched_barrier(0);
     if (kSingle) {
-      tf = prng_first<LPB>(pl, kk, kcur);
+      tf = prng_first<LPB>(pl, kk);
       // pin the half-finished state here: without it the optimiser sinks these rounds below
       // the loop's exit test, i.e. out of the stencil's latency shadow
       asm volatile("" : "+v"(tf.x0), "+v"(tf.x1));
@@ -437,7 +443,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     const uint32_t after = board[Q];
     __builtin_amdgcn_sched_barrier(0);
     // the remaining Threefry rounds hide the ds_max + read-back round trip
-    if (kSingle) u_next = prng_second<LPB>(sw, W, pl, tf, kcur);
+    if (kSingle) u_next = prng_second<LPB>(W, pl, tf);
     __builtin_amdgcn_sched_barrier(0);
     const bool won = after == wire;  // never true for a wall; a no-op for a non-moving agent
     w.P = won ? Q : P;
