@@ -105,6 +105,12 @@ __device__ __forceinline__ float bits_to_uniform(uint32_t bits) {
   return __fsub_rn(__uint_as_float((bits >> 9) | 0x3F800000u), 1.0f);
 }
 
+// The mantissa fill alone, f = 1 + uniform in [1, 2).  1 - uniform == 2 - f exactly: f - 1, 1 - x
+// and 2 - f are all exact in float32 for f a multiple of 2^-23 in [1, 2).
+__device__ __forceinline__ float bits_to_unit12(uint32_t bits) {
+  return __uint_as_float((bits >> 9) | 0x3F800000u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave / sub-wave helpers
 // ---------------------------------------------------------------------------------------------
@@ -156,6 +162,15 @@ struct SubWave {
       const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off);
       const uint64_t o = ((uint64_t)hi << 32) | lo;
       v = o < v ? o : v;
+    }
+    return v;
+  }
+
+  __device__ __forceinline__ int max_i32(int v) const {
+#pragma unroll
+    for (int off = LPB / 2; off >= 1; off >>= 1) {
+      const int o = __shfl_xor(v, off);
+      v = o > v ? o : v;
     }
     return v;
   }

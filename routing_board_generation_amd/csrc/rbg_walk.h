@@ -227,7 +227,7 @@ __device__ __forceinline__ float prng_second(uint32_t *W, const PrngLanes<LPB> &
   threefry_second_half(t, y0, y1);
   W[p.w_y0] = y0;
   W[p.w_y1] = y1;
-  return bits_to_uniform(y0);  // meaningful in the r_uni lanes
+  return bits_to_unit12(y0);  // 1 + uniform; meaningful in the r_uni lanes
 }
 
 // Start of the pipeline: the chain key goes to its W slot.
@@ -244,7 +244,7 @@ __device__ __forceinline__ float prng_round_single(uint32_t *W, const PrngLanes<
   W[p.w_y0] = y.x;
   W[p.w_y1] = y.y;
   wave_lds_fence();
-  return bits_to_uniform(y.x);
+  return bits_to_unit12(y.x);
 }
 
 // One whole round when 2N + 2 > 64 (full-wave boards with N >= 32): two or three evaluations.
@@ -261,7 +261,7 @@ __device__ __forceinline__ float prng_round_multi(uint32_t *W, int N, int lane, 
     const uint32_t c0 = r_uni ? 0u : r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
     const uint32_t c1 = r_uni ? 0u : r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
     const uint2 y = threefry_call(r_uni ? kk.x : kcur.a, r_uni ? kk.y : kcur.b, c0, c1);
-    if (r_uni) u = bits_to_uniform(y.x);
+    if (r_uni) u = bits_to_unit12(y.x);
     W[r_split ? s - N : dump] = y.x;
     W[r_split ? s : dump + 1] = y.y;
     if (base == (twoN & ~(kWaveSize - 1))) {  // wave-uniform: the call that holds slots 2N, 2N+1
@@ -334,7 +334,15 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
   board_clear<LPB>(board, g, l);
   const uint32_t wire = 3u * (uint32_t)l + 1u;
   w.r0 = w.c0 = w.r = w.c = 0;
-  w.P = pad_index(g, 0, 0);
+  // Lanes without an agent run the same branch-free loop from a word of the wall strip between
+  // two rows (second or third of its four words, rows 0 .. m-1): its four neighbours are walls,
+  // so nothing is ever "available" there, the stencil reads stay inside the board, and
+  // max(wall, wire) leaves the wall alone.  Distinct words as far as the strip allows (lanes
+  // sharing an LDS address serialise their atomics).
+  {
+    const int q = div_m(g, l);
+    w.P = pad_index(g, l - q * g.m, -3 + (q & 1));
+  }
   if (is_agent) {
     w.r0 = div_m(g, sel0);
     w.c0 = sel0 - w.r0 * g.m;
@@ -351,7 +359,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
 
   // pipeline prologue: W <- split(k_0, N), kcur <- k_1; then u <- u(0), W <- split(k_1, N), ...
   const PrngLanes<LPB> pl = prng_lanes<LPB>(N, l);
-  float u;
+  float u;  // 1 + uniform of this lane's agent for the coming iteration
   if (kSingle) {
     prng_seed(W, N, l, kcur);
     (void)prng_round_single(W, pl);
@@ -363,7 +371,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
 
   RBG_STAMP(w, 5);
   const int S = g.S;
-  const int idle_word = l % (2 * S);  // the first two padded rows are walls
+  int last_live = 0;  // last iteration (+1) in which this lane's agent could move
   // Every iteration that runs moves at least the highest-id mover of a live board into an empty
   // cell, so a board is finished after at most n - N trips; the explicit bound keeps a faulty
   // board from spinning.
@@ -402,40 +410,36 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    // (lanes without an agent sit between walls: no `is_agent` term needed)
     const bool own_ul = ul == wire, own_ur = ur == wire, own_dl = dl == wire, own_dr = dr == wire;
-    const bool a_up = is_agent && vu == 0u && !(uu == wire || own_ul || own_ur);
-    const bool a_dn = is_agent && vd == 0u && !(dd == wire || own_dl || own_dr);
-    const bool a_lf = is_agent && vl == 0u && !(ll == wire || own_ul || own_dl);
-    const bool a_rt = is_agent && vr == 0u && !(rr == wire || own_ur || own_dr);
-    const int c1 = (int)a_up, c2 = c1 + (int)a_dn, c3 = c2 + (int)a_lf, c4 = c3 + (int)a_rt;
+    const bool a_up = vu == 0u && !(uu == wire || own_ul || own_ur);
+    const bool a_dn = vd == 0u && !(dd == wire || own_dl || own_dr);
+    const bool a_lf = vl == 0u && !(ll == wire || own_ul || own_dl);
+    const bool a_rt = vr == 0u && !(rr == wire || own_ur || own_dr);
+    // cumsum(p) kept in float32 (small integers are exact): it is compared with a float below
+    const float c1 = a_up ? 1.0f : 0.0f, c2 = c1 + (a_dn ? 1.0f : 0.0f);
+    const float c3 = c2 + (a_lf ? 1.0f : 0.0f), c4 = c3 + (a_rt ? 1.0f : 0.0f);
 
     // ---- _continue_stepping (:192-203): a board stops when no agent has an available cell;
     // a finished board stays finished (its grid no longer changes), so the other boards of the
     // wave simply keep going until the last one is done.
-    const uint64_t live = __ballot(c4 > 0);
-    if (live == 0ull) break;
-    if (LPB == kWaveSize) {
-      w.iters = t + 1;
-    } else if (LPB == 32) {
-      w.iters = (sw.h ? (uint32_t)(live >> 32) : (uint32_t)live) != 0u ? t + 1 : w.iters;
-    } else {
-      w.iters = ((live >> (sw.h * LPB)) & ((1ull << (LPB & 63)) - 1ull)) != 0ull ? t + 1 : w.iters;
-    }
+    const bool mover = c4 > 0.0f;  // a blocked agent's -1 sentinel maps to NOOP / invalid UP (A.5)
+    last_live = mover ? t + 1 : last_live;
+    if (__ballot(mover) == 0ull) break;
 
     // ---- _select_action (:205-230): keys = split(key, N); choice(p = available) -----------
     // choice: cum = cumsum(p); r = cum[-1] * (1 - uniform(key_i)); first index with cum >= r.
-    const float rsel = __fmul_rn((float)c4, __fsub_rn(1.0f, u));
+    // u12 = 1 + uniform, and 1 - uniform == 2 - u12 exactly (rbg_device.h::bits_to_unit12)
+    const float rsel = __fmul_rn(c4, __fsub_rn(2.0f, u));
     int dir = 3;
-    if ((float)c3 >= rsel) dir = 2;
-    if ((float)c2 >= rsel) dir = 1;
-    if ((float)c1 >= rsel) dir = 0;
-    const bool mover = c4 > 0;  // a blocked agent's -1 sentinel maps to NOOP / invalid UP (A.5)
+    if (c3 >= rsel) dir = 2;
+    if (c2 >= rsel) dir = 1;
+    if (c1 >= rsel) dir = 0;
     // step = signed byte `dir` of [-S, +S, -1, +1]: one shift + one v_bfe_i32
     const int dP = __builtin_amdgcn_sbfe((int)g.step_table, (uint32_t)dir * 8u, 8u);
-    // branch-free: a non-moving agent "claims" its own head cell (already = wire), the other lanes
-    // one wall word each (max(wall, wire) = wall) -- distinct addresses, because same-address LDS
-    // atomics from many lanes serialise
-    const int Q = mover ? P + dP : is_agent ? P : idle_word;
+    // branch-free: a lane that does not move "claims" the word it stands on -- its own head cell
+    // (already = wire) or its wall word (max(wall, wire) = wall)
+    const int Q = mover ? P + dP : P;
 
     // ---- _step_agents (:101-145): contested cell -> highest id wins, losers stay ----------
     atomicMax(&board[Q], wire);
@@ -451,6 +455,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
   }
   RBG_STAMP(w, 6);
+  w.iters = sw.max_i32(last_live);  // while_loop trip count of this lane's board
 
   unpad_index(g, w.P, w.r, w.c);  // the loop tracks the padded index only
   // update_solved_board_with_head_target_encodings (:435-447): heads first, then targets
