@@ -747,3 +747,35 @@ def test_multi_to_single_aggregates_inside_the_launch(rbg, oracle, donate, prefe
     assert seen_nonzero > B
     for sess in env.unwrapped._sessions.values():
         sess.drain()
+
+
+# ------------------------------------------------------------------------------ many boards
+SWEEP = [  # (m, N, log2 B at scale 1): all three sub-wave widths, both Threefry pipelines, the
+    # register / LDS variants of the start-cell shuffle, odd and even cell counts
+    (16, 10, 17), (8, 5, 15), (10, 5, 15), (12, 7, 14), (16, 15, 13), (32, 20, 12), (22, 12, 12),
+    (23, 12, 12), (40, 15, 10), (9, 7, 13), (5, 6, 13), (20, 31, 11), (20, 32, 10),
+]
+
+
+@pytest.mark.parametrize("m,N,log2b", SWEEP)
+def test_many_boards_match_oracle(rbg, oracle, torch_mod, m, N, log2b):
+    """Rare paths (threshold retries of the start-cell shuffle, long walks, collisions) only show
+    up in large samples.  RBG_SWEEP_SCALE=8 multiplies the batch sizes (2.1 M boards, ~20 s)."""
+    import os
+
+    from routing_board_generation_amd import ops
+
+    B = (1 << log2b) * int(os.environ.get("RBG_SWEEP_SCALE", "1"))
+    keys_all = oracle.split(oracle.prng_key(1000 + m * 64 + N), B)
+    for lo in range(0, B, 65536):
+        kn = keys_all[lo:lo + 65536]
+        kt = torch_mod.from_numpy(kn.view(np.int32)).cuda().view(torch_mod.uint32)
+        out = ops.prw_generate(kt, m, N, split_first=True, want_solved=True, want_train=True,
+                               want_state=True, want_iters=True)
+        st, solved, iters = oracle.generate_batch(kn, m, N, threads=16)
+        assert (to_np(out["solved_grid"]) == solved).all()
+        assert (to_np(out["train_grid"]) == st["grid"]).all()
+        assert (to_np(out["start"]) == st["start"]).all()
+        assert (to_np(out["target"]) == st["target"]).all()
+        assert (to_np(out["iters"]) == iters).all()
+        assert (to_np(out["key_out"]) == st["key"]).all()
