@@ -64,6 +64,41 @@ def main():
     json.dump({"tag": tag, "kernels": summary},
               open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
+    issue = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_issue", "*", "*_counter_collection.csv"))
+    if issue:
+        write_issue(tag, issue[0], out)
+
+
+def write_issue(tag, path, out):
+    """SQ instruction / cycle counters per kernel (one more --pmc pass): how busy the vector
+    issue ports are.  SQ_WAVE_CYCLES, SQ_ACTIVE_INST_* and SQ_WAIT_* count quad-cycles
+    (MI355X_MICROARCH.md, constants table)."""
+    names = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES",
+             "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY")
+    per = {n: per_kernel(path, n) for n in names}
+    lines = [f"# Issue counters per launch ({tag})", "",
+             "rocprofv3 --pmc " + " ".join(names) + " (one pass; medians over the launches of one",
+             "bench.py run, B = 4096, 16x16/10).  Cycle counters are quad-cycles.", "",
+             "| kernel | waves | VALU | SALU | LDS | instr / wave | wave quad-cycles | active any | "
+             "waiting (s_waitcnt) | VALU quad-cycles / wave quad-cycles |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
+    for k in sorted(per["SQ_WAVES"]):
+        if "anonymous namespace" not in k:
+            continue
+        med = {n: sorted(per[n].get(k, [0.0]))[len(per[n].get(k, [0.0])) // 2] for n in names}
+        if med["SQ_WAVES"] == 0:
+            continue
+        name = k.split("(anonymous namespace)::")[1].split("(")[0]
+        total = med["SQ_INSTS_VALU"] + med["SQ_INSTS_SALU"] + med["SQ_INSTS_LDS"]
+        wc = max(med["SQ_WAVE_CYCLES"], 1.0)
+        lines.append(f"| {name} | {med['SQ_WAVES']:.0f} | {med['SQ_INSTS_VALU']:.0f} | "
+                     f"{med['SQ_INSTS_SALU']:.0f} | {med['SQ_INSTS_LDS']:.0f} | "
+                     f"{total / med['SQ_WAVES']:.0f} | {wc:.0f} | "
+                     f"{med['SQ_ACTIVE_INST_ANY'] / wc:.2f} | {med['SQ_WAIT_ANY'] / wc:.2f} | "
+                     f"{med['SQ_ACTIVE_INST_VALU'] / wc:.2f} |")
+    lines.append("")
+    open(os.path.join(out, f"{tag}_issue.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
 
 
 if __name__ == "__main__":
