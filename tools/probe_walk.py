@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--times", action="store_true",
                     help="probe build that records every wave's start and end time (s_memtime): "
                          "start delay and duration by block index for one launch of 4096 boards")
+    ap.add_argument("--subsets", action="store_true",
+                    help="time subsets / orderings of the C2 keys (longest pair alone, sorted by "
+                         "walk length, ...): what bounds the launch")
     ap.add_argument("--batches", type=str, default="64,256,1024,2048,4096,8192,16384,65536")
     args = ap.parse_args()
     print(f"# {args.m}x{args.m}/{args.n}: kernel time (us, p50) vs batch")
@@ -89,6 +92,43 @@ def main():
         probe_placement(args)
     if args.times:
         probe_times(args)
+    if args.subsets:
+        probe_subsets(args)
+
+
+def probe_subsets(args):
+    m, N = args.m, args.n
+    keys = rbg.split(rbg.PRNGKey(0), 4096)
+    full = ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_state=True,
+                            want_iters=True)
+    it = full["iters"].cpu()
+    order = torch.argsort(it)
+
+    def timeit(idx, reps=300):
+        k = keys.view(torch.int32)[idx.to(keys.device)].contiguous().view(torch.uint32)
+        out = ops.prw_generate(k, m, N, split_first=True, want_solved=False, want_state=True,
+                               want_iters=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.prw_generate(k, m, N, split_first=True, want_solved=False, want_state=True,
+                             want_iters=True, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3, int(out["iters"].max()), float(out["iters"].float().mean())
+
+    pm = torch.maximum(it[0::2], it[1::2])
+    po = torch.argsort(pm, descending=True)
+    cases = (("longest pair alone", order[-2:]), ("median pair alone", order[2047:2049]),
+             ("shortest pair alone", order[:2]), ("2048 longest boards", order[-2048:]),
+             ("2048 shortest boards", order[:2048]), ("all 4096, natural order", torch.arange(4096)),
+             ("all 4096, sorted by T descending", order.flip(0)),
+             ("all 4096, natural pairs ordered by max T descending",
+              torch.stack([2 * po, 2 * po + 1], 1).reshape(-1)))
+    for name, idx in cases:
+        us, mx, mean = timeit(idx)
+        print(f"{name:52s} B={idx.numel():5d} {us:7.2f} us  max T {mx:3d}  mean T {mean:5.1f}")
 
 
 def probe_times(args):
