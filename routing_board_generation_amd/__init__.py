@@ -4,7 +4,7 @@ reset/step, behind the reference's Generator / Environment API.
 Importing this package never touches the GPU and never falls back to a CPU path: the first call
 that needs compute loads lib/librbg_prw.so and raises if it is missing.
 """
-from . import _native  # noqa: F401
+from . import _native, specs  # noqa: F401
 from .board_generation.parallel_random_walk import ParallelRandomWalkBoard  # noqa: F401
 from .connector import (Connector, DenseRewardFn, MultiToSingleWrapper,  # noqa: F401
                         VmapAutoResetWrapper)

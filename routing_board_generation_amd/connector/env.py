@@ -17,7 +17,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from .. import ops
+from .. import ops, specs
 from ..online_generators.parallel_random_walk_generator import ParallelRandomWalkGenerator
 from ..online_generators.uniform_generator import Generator, UniformRandomGenerator
 from ..types import Agent, Observation, State, TimeStep
@@ -122,6 +122,28 @@ class Connector:
                 auto_reset=fused_reset, refill_every=self._prefetch_delay, donate=self._donate,
                 aggregate=self._aggregate)
         return sess
+
+    # ---------------------------------------------------------------------------------- specs
+    def observation_spec(self) -> "specs.Spec[Observation]":
+        """[3P] Connector.observation_spec: one env (no batch axis), per-agent views."""
+        N, m = self.num_agents, self.grid_size
+        return specs.Spec(
+            Observation, "ObservationSpec",
+            grid=specs.BoundedArray((N, m, m), torch.int32, 0, 3 * N, "grid"),
+            action_mask=specs.BoundedArray((N, 5), torch.bool, False, True, "action_mask"),
+            step_count=specs.BoundedArray((), torch.int32, 0, self.time_limit, "step_count"))
+
+    def action_spec(self) -> "specs.MultiDiscreteArray":
+        """One of NOOP / UP / RIGHT / DOWN / LEFT per agent."""
+        return specs.MultiDiscreteArray([5] * self.num_agents, torch.int32, "action")
+
+    def reward_spec(self) -> "specs.Array":
+        shape = () if self._aggregate else (self.num_agents,)
+        return specs.Array(shape, torch.float32, "reward")
+
+    def discount_spec(self) -> "specs.BoundedArray":
+        shape = () if self._aggregate else (self.num_agents,)
+        return specs.BoundedArray(shape, torch.float32, 0.0, 1.0, "discount")
 
     # ---------------------------------------------------------------------------------- reset
     def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
