@@ -164,19 +164,24 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
 /* ---- auto-reset without the walk on the step's critical path --------------------------------
  * VmapAutoResetWrapper restarts a finished episode from split(state.key)[0], and state.key does
  * not change during an episode: the next episode's State is known as soon as the current one
- * starts.  A stash holds that State per env, produced by rbg_stash_refill on a SIDE stream while
- * the main stream keeps stepping; the step then copies it instead of walking.
+ * starts.  A stash holds that State per env, produced by rbg_stash_refill in ONE launch for all
+ * the envs that restarted recently (a throughput-shaped batch of walks) instead of by every step
+ * launch for its own few finished envs (a launch that lasts as long as its longest walk); the
+ * step then copies 1.3 KB instead of walking.
  *   next        a full rbg_state for B envs: next[b] = reset(split(tag[b])[0])
  *   tag         uint32 [B][2]: the State.key next[b] was generated for (zero-initialised)
  *   ready_at    int32 [B]: first launch tick that may consume the entry (zero-initialised)
  *   refill_key  uint32 [B][2]: State.key of the running episode, i.e. the entry wanted next
  *   hits        int32 [B], nullable: resets served from the stash (diagnostics; caller zeroes)
  * Protocol (host-driven, kernel boundaries only -- no in-kernel cross-stream flags):
- *   every reset/step launch has a tick t = 0, 1, 2, ...; it is followed by rbg_stash_refill R_t
- *   on the side stream (which waits for the launch).  A launch that (re)starts env b writes
- *   refill_key[b] and ready_at[b] = t + ready_delay; launch t must wait (stream event) for
- *   R_{t - ready_delay} before it starts.  An entry is consumed only if tick >= ready_at[b] and
- *   tag[b] == state.key[b]; otherwise the walk runs inline, so results never depend on timing. */
+ *   every reset/step launch has a tick t = 0, 1, 2, ...  A launch that (re)starts env b writes
+ *   refill_key[b] and ready_at[b] = t + ready_delay, where the caller guarantees that a refill
+ *   launched after launch t has completed before launch t + ready_delay starts.  With the
+ *   refill on the launches' own stream every K launches that is the next multiple of K (stream
+ *   order, no events; what routing_board_generation_amd.ops.EpochStash does by default); with
+ *   the refill on a side stream it takes a stream event.  An entry is consumed only if
+ *   tick >= ready_at[b] and tag[b] == state.key[b]; otherwise the walk runs inline, so results
+ *   never depend on timing. */
 typedef struct rbg_stash {
   rbg_state next;
   uint32_t *tag;

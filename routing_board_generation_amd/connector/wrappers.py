@@ -44,10 +44,11 @@ class VmapAutoResetWrapper(_Wrapper):
     the same kernel launch from split(state.key)[0], keeping reward/discount/step_type/extras of
     the terminal step and replacing only the observation."""
 
-    def __init__(self, env, prefetch: bool = False, prefetch_delay: int = 8, donate=None):
-        """prefetch=True generates every env's NEXT episode ahead of time on a side stream
-        (include/rbg_prw.h::rbg_stash), so that a step never waits for a random walk; results are
-        identical with and without it.  One refill runs per `prefetch_delay` launches.
+    def __init__(self, env, prefetch: bool = False, prefetch_delay: int = 16, donate=None):
+        """prefetch=True generates every env's NEXT episode ahead of time
+        (include/rbg_prw.h::rbg_stash): one refill launch per `prefetch_delay` steps walks for all
+        the envs that restarted since the last one, instead of every step launch waiting for the
+        walks of its own finished envs; results are identical with and without it.
         donate=True/False overrides the env's setting (Connector(donate=...))."""
         super().__init__(env)
         env.unwrapped._auto_reset = True

@@ -626,10 +626,13 @@ def test_prefetched_auto_reset_async_stress(rbg, torch_mod):
     assert hits > 10 * B, hits
 
 
-@pytest.mark.parametrize("K,fuse", [(0, False), (3, False), (3, True), (0, True), (5, True)])
-def test_step_loop_equals_validated_path(rbg, torch_mod, K, fuse):
-    """ops.StepLoop (prebuilt launch descriptors, optional epoch stash, optional fused policy) is
-    the same function as { random_actions; connector_step(auto_reset) } step by step."""
+@pytest.mark.parametrize("K,fuse,serial", [(0, False, True), (3, False, True), (3, True, True),
+                                           (0, True, True), (5, True, True), (3, False, False),
+                                           (4, True, False)])
+def test_step_loop_equals_validated_path(rbg, torch_mod, K, fuse, serial):
+    """ops.StepLoop (prebuilt launch descriptors, optional epoch stash refilled on the same or on
+    a side stream, optional fused policy) is the same function as { random_actions;
+    connector_step(auto_reset) } step by step."""
     from routing_board_generation_amd import ops
 
     m, N, B, steps, tl = 16, 10, 1024, 150, 11
@@ -639,7 +642,8 @@ def test_step_loop_equals_validated_path(rbg, torch_mod, K, fuse):
         act = ops.random_actions(pkeys, t, rts["action_mask"])
         ref, rts = ops.connector_step(ref, act, time_limit=tl, auto_reset=True)
     st, ts = ops.alloc_state(B, m, N, "cuda"), ops.alloc_timestep(B, m, N, "cuda")
-    loop = ops.StepLoop(st, ts, pkeys, time_limit=tl, refill_every=K, fuse_policy=fuse)
+    loop = ops.StepLoop(st, ts, pkeys, time_limit=tl, refill_every=K, fuse_policy=fuse,
+                        serial_refill=serial)
     loop.reset(keys)
     for t in range(steps):
         loop.step(t)
