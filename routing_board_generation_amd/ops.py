@@ -325,50 +325,11 @@ def connector_step_prefetch(state: StateBufs, action: torch.Tensor, stash: dict,
 
 
 def stash_refill(stash: dict, m: int) -> None:
-    """Launch the refill on torch's CURRENT stream (callers put it on a side stream)."""
+    """Launch the refill on torch's current stream."""
     B, N = stash["next"]["start"].shape[0], stash["next"]["start"].shape[1]
     dev = stash["tag"].device
     h = _stash_struct(stash, B, m, N)
     nat.check(nat.lib().rbg_stash_refill(B, m, N, C.byref(h), _stream(dev)), "rbg_stash_refill")
-
-
-class Prefetcher:
-    """Host side of the stash protocol (include/rbg_prw.h::rbg_stash): numbers the reset/step
-    launches (ticks), runs rbg_stash_refill after each of them on a side stream, and makes launch
-    t wait for the refill of launch t - delay -- all through stream events."""
-
-    def __init__(self, B: int, m: int, N: int, device, delay: int = 4) -> None:
-        self.m, self.delay = m, max(1, int(delay))
-        self.stash = alloc_stash(B, m, N, device)
-        self.sides = [torch.cuda.Stream(device=device) for _ in range(min(self.delay, 4))]
-        self.tick = 0
-        self._refill_done = {}
-
-    def before_launch(self) -> int:
-        """Call right before a reset/step launch on the current stream; returns its tick."""
-        ev = self._refill_done.pop(self.tick - self.delay, None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-        return self.tick
-
-    def after_launch(self) -> None:
-        """Call right after the launch: queue the refill behind it on the side stream."""
-        launched = torch.cuda.Event()
-        launched.record(torch.cuda.current_stream())
-        side = self.sides[self.tick % len(self.sides)]  # consecutive refills overlap each other
-        side.wait_event(launched)
-        with torch.cuda.stream(side):
-            stash_refill(self.stash, self.m)
-            done = torch.cuda.Event()
-            done.record(side)
-        self._refill_done[self.tick] = done
-        self.tick += 1
-
-    def drain(self) -> None:
-        """Make the current stream wait for every refill in flight (before freeing buffers)."""
-        for ev in self._refill_done.values():
-            torch.cuda.current_stream().wait_event(ev)
-        self._refill_done.clear()
 
 
 class EpochStash:

@@ -593,9 +593,12 @@ def test_step_accepts_states_it_did_not_return(rbg, torch_mod):
         env.step(s1, a1[:, :3])
 
 
-def test_prefetched_auto_reset_async_stress(rbg, torch_mod):
-    """400 steps of 4096 envs without any host synchronisation (refills genuinely overlap later
-    steps): the prefetching path must end in exactly the state of the inline path."""
+@pytest.mark.parametrize("serial", [True, False])
+def test_prefetched_auto_reset_async_stress(rbg, torch_mod, serial):
+    """400 steps of 4096 envs without any host synchronisation, through the validated
+    ops.connector_*_prefetch calls driven by ops.EpochStash (refill on the same stream, or on a
+    side stream where it genuinely overlaps later steps): the stash path must end in exactly the
+    state of the inline path."""
     from routing_board_generation_amd import ops
 
     m, N, B, steps, tl = 16, 10, 4096, 400, 9
@@ -605,24 +608,24 @@ def test_prefetched_auto_reset_async_stress(rbg, torch_mod):
     for t in range(steps):
         ops.random_actions(akeys, t, ts_a["action_mask"], out=act)
         ops.connector_step(st_a, act, time_limit=tl, auto_reset=True, state_out=st_a, timestep=ts_a)
-    pf = ops.Prefetcher(B, m, N, keys.device, delay=3)
-    tick = pf.before_launch()
-    st_b, ts_b = ops.connector_reset_prefetch(keys, m, N, pf.stash, tick, pf.delay)
-    pf.after_launch()
+    ep = ops.EpochStash(B, m, N, keys.device, every=3, serial=serial)
+    ep.before_launch()
+    st_b, ts_b = ops.connector_reset_prefetch(keys, m, N, ep.stash, ep.tick, ep.ready_delay())
+    ep.after_launch()
     for t in range(steps):
         ops.random_actions(akeys, t, ts_b["action_mask"], out=act)
-        tick = pf.before_launch()
-        ops.connector_step_prefetch(st_b, act, pf.stash, tick, pf.delay, time_limit=tl,
+        ep.before_launch()
+        ops.connector_step_prefetch(st_b, act, ep.stash, ep.tick, ep.ready_delay(), time_limit=tl,
                                     state_out=st_b, timestep=ts_b)
-        pf.after_launch()
-    pf.drain()
+        ep.after_launch()
+    ep.drain()
     torch_mod.cuda.synchronize()
     for k in ("grid", "step_count", "start", "target", "position"):
         assert torch_mod.equal(st_a[k], st_b[k]), k
     assert torch_mod.equal(st_a["key"].view(torch_mod.int32), st_b["key"].view(torch_mod.int32))
     assert torch_mod.equal(ts_a["obs_grid"], ts_b["obs_grid"])
     assert torch_mod.equal(ts_a["reward"], ts_b["reward"])
-    hits = int(pf.stash["hits"].sum().item())
+    hits = int(ep.stash["hits"].sum().item())
     assert hits > 10 * B, hits
 
 

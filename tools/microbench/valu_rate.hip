@@ -28,6 +28,29 @@ OP_KERNEL(k_xad, "v_xad_u32 %0, %0, %2, %3\n v_xad_u32 %1, %1, %3, %2")
 OP_KERNEL(k_perm, "v_perm_b32 %0, %0, %0, %2\n v_perm_b32 %1, %1, %1, %3")
 OP_KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %1, %1, %3, vcc")
 OP_KERNEL(k_mul_lo, "v_mul_lo_u32 %0, %0, %2\n v_mul_lo_u32 %1, %1, %3")
+OP_KERNEL(k_mul_hi, "v_mul_hi_u32 %0, %0, %2\n v_mul_hi_u32 %1, %1, %3")
+
+// Philox-4x32-10 (Salmon et al., SC'11), the generator BASELINE.json's north_star names: two
+// 32x32 -> 64 multiplies per round.  Timed next to Threefry-2x32-20 to price a random word on
+// this chip (Philox yields four words per evaluation, Threefry two).
+__global__ void k_philox(uint32_t *out, int reps) {
+  uint32_t c0 = threadIdx.x, c1 = blockIdx.x, c2 = c0 ^ 0x1234u, c3 = c1 + 77u;
+  for (int i = 0; i < reps; ++i) {
+    uint32_t k0 = 0xA4093822u, k1 = 0x299F31D0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+      const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      c0 = hi1 ^ c1 ^ k0;
+      c1 = lo1;
+      c2 = hi0 ^ c3 ^ k1;
+      c3 = lo0;
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = c0 + c1 + c2 + c3;
+}
 
 __global__ void k_threefry(uint32_t *out, int reps) {
   uint32_t a = threadIdx.x, b = blockIdx.x, c = a ^ 0x1234u, d = b + 77u;
@@ -74,7 +97,10 @@ int main() {
     run("perm", k_perm, blocks, 4000, 32);
     run("cndmask", k_cndmask, blocks, 4000, 32);
     run("mul_lo", k_mul_lo, blocks, 4000, 32);
-    run("threefry", k_threefry, blocks, 2000, 82);
+    run("mul_hi", k_mul_hi, blocks, 4000, 32);
+    run("threefry", k_threefry, blocks, 2000, 82);  // ~82 instructions per evaluation
+    run("3fry/eval", k_threefry, blocks, 2000, 1);  // cycles per evaluation (2 words)
+    run("philox/ev", k_philox, blocks, 2000, 1);    // cycles per evaluation (4 words)
   }
   return 0;
 }
