@@ -255,6 +255,7 @@ __device__ __forceinline__ void request_refill(const StashPtrs &st, int b, int l
 
 __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
+  const SubWave<64> sw(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;
   if (b >= a.B) return;
@@ -268,31 +269,31 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     Key2 kin;
     kin.a = a.keys[2 * (size_t)b];
     kin.b = a.keys[2 * (size_t)b + 1];
-    const Key2 key = regenerate(board, W, g, N, lane, kin, ag);
-    store_state(board, g, N, b, lane, ag, 0, key, a.out);
+    const Key2 key = regenerate(sw, board, W, g, N, kin, ag);
+    store_state(sw, board, g, N, b, ag, 0, key, a.out);
     request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
-    write_observation(board, g, N, b, lane, ag, 0, a.ts);
-    write_extras(board, g, N, b, lane, ag, a.ts);
+    write_observation(sw, board, g, N, b, ag, 0, a.ts);
+    write_extras(sw, board, g, N, b, ag, a.ts);
     write_restart(N, b, lane, a.ts);
     return;
   }
 
   int step_count;
   Key2 key;
-  load_state(board, g, N, b, lane, a.in, ag, step_count, key);
+  load_state(sw, board, g, N, b, a.in, ag, step_count, key);
 
   if (a.mode == 1) {  // ---- observe an existing state (restart timestep) ----------------------
-    write_observation(board, g, N, b, lane, ag, step_count, a.ts);
-    write_extras(board, g, N, b, lane, ag, a.ts);
+    write_observation(sw, board, g, N, b, ag, step_count, a.ts);
+    write_extras(sw, board, g, N, b, ag, a.ts);
     write_restart(N, b, lane, a.ts);
     return;
   }
 
   // ---- Connector.step --------------------------------------------------------------------------
   const int act = lane < N ? a.action[(size_t)b * N + lane] : 0;
-  const StepResult res = env_step_core(board, g, N, lane, ag, step_count, act, a.p.time_limit);
-  write_step_outcome(res, a.p, N, b, lane, a.ts);
-  write_extras(board, g, N, b, lane, ag, a.ts);
+  const StepResult res = env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit);
+  write_step_outcome(sw, res, a.p, N, b, a.ts);
+  write_extras(sw, board, g, N, b, ag, a.ts);
 
   if (res.last && a.p.auto_reset) {
     // VmapAutoResetWrapper._auto_reset: key, _ = split(state.key); state, ts = reset(key);
@@ -307,18 +308,18 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
       hit = a.tick >= a.stash.ready_at[b] && tag.x == key.a && tag.y == key.b;
     }
     if (hit) {
-      load_state(board, g, N, b, lane, a.stash.next, ag, step_count, key);
+      load_state(sw, board, g, N, b, a.stash.next, ag, step_count, key);
       if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
     } else {
       Key2 rk, unused;
-      split2_lanes(SubWave<64>(lane), key, rk, unused);
-      key = regenerate(board, W, g, N, lane, rk, ag);
+      split2_lanes(sw, key, rk, unused);
+      key = regenerate(sw, board, W, g, N, rk, ag);
     }
     step_count = 0;
     request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
   }
-  store_state(board, g, N, b, lane, ag, step_count, key, a.out);
-  write_observation(board, g, N, b, lane, ag, step_count, a.ts);
+  store_state(sw, board, g, N, b, ag, step_count, key, a.out);
+  write_observation(sw, board, g, N, b, ag, step_count, a.ts);
 }
 
 // Side-stream producer of the stash: for every env whose entry is not the one its running
@@ -331,6 +332,7 @@ struct RefillArgs {
 
 __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
+  const SubWave<64> sw(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;
   if (b >= a.B) return;
@@ -342,9 +344,9 @@ __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
   const Geo g = a.g;
   AgentRegs ag = {0, 0, 0, 0, 0, 0};
   Key2 key = {want.x, want.y}, rk, unused;
-  split2_lanes(SubWave<64>(lane), key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
-  const Key2 next_key = regenerate(board, W, g, a.N, lane, rk, ag);
-  store_state(board, g, a.N, b, lane, ag, 0, next_key, a.stash.next);
+  split2_lanes(sw, key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
+  const Key2 next_key = regenerate(sw, board, W, g, a.N, rk, ag);
+  store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
   if (lane == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
 }
 
@@ -379,6 +381,7 @@ struct RolloutArgs {
 // (4 waves per SIMD = one launch of 4096 envs resident at once: keep the VGPR budget at 128)
 __global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
+  const SubWave<64> sw(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kWavesPerBlock + wib;
   if (b >= a.B) return;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArg
   AgentRegs ag = {0, 0, 0, 0, 0, 0};
   int step_count;
   Key2 key, pk;
-  load_state(board, g, N, b, lane, a.in, ag, step_count, key);
+  load_state(sw, board, g, N, b, a.in, ag, step_count, key);
   pk.a = a.policy_keys[2 * (size_t)b];
   pk.b = a.policy_keys[2 * (size_t)b + 1];
 
@@ -399,19 +402,19 @@ __global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArg
   uint32_t bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
   for (int s = 0; s < a.n_steps; ++s) {
     const int act = random_policy_action(pk, a.t0 + (uint32_t)s, (uint32_t)lane, bits);
-    const StepResult res = env_step_core(board, g, N, lane, ag, step_count, act, a.p.time_limit);
+    const StepResult res = env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit);
     bits = res.bits;
     conn_made += __popcll(__ballot(!res.was_connected && res.connected));
     pen_steps += __popcll(__ballot(is_agent && !res.was_connected));
     const bool final_step = s == a.n_steps - 1;
     if (final_step) {
-      write_step_outcome(res, a.p, N, b, lane, a.ts);
-      write_extras(board, g, N, b, lane, ag, a.ts);
+      write_step_outcome(sw, res, a.p, N, b, a.ts);
+      write_extras(sw, board, g, N, b, ag, a.ts);
     }
     if (res.last) {
       episodes += 1;
       fin_conn += __popcll(__ballot(res.connected));
-      if (a.stats.final_path_length) fin_plen += count_path_cells(board, g, lane);
+      if (a.stats.final_path_length) fin_plen += count_path_cells(sw, board, g);
       if (a.p.auto_reset) {
         bool hit = false;
         if (a.stash.tag && !used_stash) {
@@ -419,13 +422,13 @@ __global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArg
           hit = a.tick >= a.stash.ready_at[b] && tag.x == key.a && tag.y == key.b;
         }
         if (hit) {
-          load_state(board, g, N, b, lane, a.stash.next, ag, step_count, key);
+          load_state(sw, board, g, N, b, a.stash.next, ag, step_count, key);
           used_stash = true;  // the entry is consumed; later resets of this launch walk inline
           if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
         } else {
           Key2 rk, unused;
-          split2_lanes(SubWave<64>(lane), key, rk, unused);
-          key = regenerate(board, W, g, N, lane, rk, ag);
+          split2_lanes(sw, key, rk, unused);
+          key = regenerate(sw, board, W, g, N, rk, ag);
         }
         step_count = 0;
         request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
@@ -433,8 +436,8 @@ __global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArg
       }
     }
   }
-  store_state(board, g, N, b, lane, ag, step_count, key, a.out);
-  write_observation(board, g, N, b, lane, ag, step_count, a.ts);
+  store_state(sw, board, g, N, b, ag, step_count, key, a.out);
+  write_observation(sw, board, g, N, b, ag, step_count, a.ts);
   if (lane == 0) {
     if (a.stats.episodes) a.stats.episodes[b] = episodes;
     if (a.stats.connections_made) a.stats.connections_made[b] = conn_made;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void dataset_sample_kernel(DatasetArgs a) {
   wave_lds_fence();
   if (lane < a.N) board[pad_index(g, ag.tr, ag.tc)] = 3u * lane + 3u;  // targets written last
   wave_lds_fence();
-  store_state(board, g, a.N, b, lane, ag, 0, k0, a.out);
+  store_state(sw, board, g, a.N, b, ag, 0, k0, a.out);
   if (lane == 0 && a.which) a.which[b] = (int32_t)which;
 }
 

@@ -1,5 +1,7 @@
-// rbg_env.h -- Connector environment pieces on an LDS-resident env (one env per wavefront):
-// state load/store, action mask, observation, extras, one step, regeneration.
+// rbg_env.h -- Connector environment pieces on an LDS-resident env, one env per sub-wave of LPB
+// lanes (rbg_device.h::SubWave; sub-lane i < N = agent i): state load/store, action mask,
+// observation, extras, one step, regeneration.  Everything that crosses lanes stays inside the
+// sub-wave, so the envs of a wave may diverge (one finishing an episode while the other steps on).
 // Semantics: [3P] jumanji==0.2.2 jumanji/environments/routing/connector/{env,utils,reward}.py and
 // jumanji/wrappers.py (see DESIGN.md section 2 for what is pinned and what is project-defined).
 #pragma once
@@ -10,19 +12,21 @@
 namespace rbg {
 
 // HBM int32 grid -> padded LDS board
-__device__ __forceinline__ void load_grid(uint32_t *board, const Geo &g, int lane,
+template <int LPB>
+__device__ __forceinline__ void load_grid(const SubWave<LPB> &sw, uint32_t *board, const Geo &g,
                                           const int32_t *__restrict__ in) {
-  for (int w = lane; w < g.words; w += kWaveSize) board[w] = kWall;
+  const int lane = sw.l;
+  for (int w = lane; w < g.words; w += LPB) board[w] = kWall;
   wave_lds_fence();
   if ((g.m & 3) == 0) {
-    for (int idx = lane * 4; idx < g.n; idx += kWaveSize * 4) {
+    for (int idx = lane * 4; idx < g.n; idx += LPB * 4) {
       const int r = div_m(g, idx);
       const int4 v = *reinterpret_cast<const int4 *>(&in[idx]);
       *reinterpret_cast<uint4 *>(&board[pad_index(g, r, idx - r * g.m)]) =
           make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
     }
   } else {
-    for (int idx = lane; idx < g.n; idx += kWaveSize) {
+    for (int idx = lane; idx < g.n; idx += LPB) {
       const int r = div_m(g, idx);
       board[pad_index(g, r, idx - r * g.m)] = (uint32_t)in[idx];
     }
@@ -63,11 +67,12 @@ __device__ __forceinline__ int obs_value(uint32_t v, int i3, int n3) {
   return v == 0u ? 0 : t + 1;
 }
 
-__device__ __forceinline__ void store_obs(const uint32_t *board, const Geo &g, int N, int lane,
-                                          int32_t *__restrict__ obs) {
-  const int n3 = 3 * N;
+template <int LPB>
+__device__ __forceinline__ void store_obs(const SubWave<LPB> &sw, const uint32_t *board,
+                                          const Geo &g, int N, int32_t *__restrict__ obs) {
+  const int n3 = 3 * N, lane = sw.l;
   if ((g.m & 3) == 0) {
-    for (int idx = lane * 4; idx < g.n; idx += kWaveSize * 4) {
+    for (int idx = lane * 4; idx < g.n; idx += LPB * 4) {
       const int r = div_m(g, idx);
       const uint4 v = *reinterpret_cast<const uint4 *>(&board[pad_index(g, r, idx - r * g.m)]);
       for (int i = 0; i < N; ++i) {
@@ -83,7 +88,7 @@ __device__ __forceinline__ void store_obs(const uint32_t *board, const Geo &g, i
       }
     }
   } else {
-    for (int idx = lane; idx < g.n; idx += kWaveSize) {
+    for (int idx = lane; idx < g.n; idx += LPB) {
       const int r = div_m(g, idx);
       const uint32_t v = board[pad_index(g, r, idx - r * g.m)];
       for (int i = 0; i < N; ++i) obs[(size_t)i * g.n + idx] = obs_value(v, 3 * i, n3);
@@ -92,13 +97,15 @@ __device__ __forceinline__ void store_obs(const uint32_t *board, const Geo &g, i
 }
 
 // number of PATH cells (v % 3 == 1), the `total_path_length` extra
-__device__ __forceinline__ int count_path_cells(const uint32_t *board, const Geo &g, int lane) {
+template <int LPB>
+__device__ __forceinline__ int count_path_cells(const SubWave<LPB> &sw, const uint32_t *board,
+                                                const Geo &g) {
   int cnt = 0;
-  for (int idx = lane; idx < g.n; idx += kWaveSize) {
+  for (int idx = sw.l; idx < g.n; idx += LPB) {
     const int r = div_m(g, idx);
     cnt += (int)(board[pad_index(g, r, idx - r * g.m)] % 3u == 1u);
   }
-  return SubWave<64>(lane).sum_i32(cnt);
+  return sw.sum_i32(cnt);
 }
 
 struct TimestepPtrs {
@@ -146,8 +153,10 @@ __device__ __forceinline__ void store_agents(const StatePtrs &st, int b, int N, 
 
 // Builds a fresh State from a finished walk (parallel_random_walk_generator.py:58-77) and turns
 // the LDS board into the training grid (heads + targets only).
-__device__ __forceinline__ void board_to_training(uint32_t *board, const Geo &g, int lane) {
-  for (int idx = lane; idx < g.n; idx += kWaveSize) {
+template <int LPB>
+__device__ __forceinline__ void board_to_training(const SubWave<LPB> &sw, uint32_t *board,
+                                                  const Geo &g) {
+  for (int idx = sw.l; idx < g.n; idx += LPB) {
     const int r = div_m(g, idx);
     const int p = pad_index(g, r, idx - r * g.m);
     const uint32_t v = board[p];
@@ -158,21 +167,25 @@ __device__ __forceinline__ void board_to_training(uint32_t *board, const Geo &g,
 
 // Observation + extras of the state held in (board, ag); `terminal` keeps reward/discount/
 // step_type/extras of the step that just ended when the env was auto-reset.
-__device__ __forceinline__ void write_observation(const uint32_t *board, const Geo &g, int N,
-                                                  int b, int lane, const AgentRegs &ag,
+template <int LPB>
+__device__ __forceinline__ void write_observation(const SubWave<LPB> &sw, const uint32_t *board,
+                                                  const Geo &g, int N, int b, const AgentRegs &ag,
                                                   int step_count, const TimestepPtrs &ts) {
+  const int lane = sw.l;
   const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
   store_mask(ts, b, N, lane, bits);
-  if (ts.obs_grid) store_obs(board, g, N, lane, ts.obs_grid + (size_t)b * N * g.n);
+  if (ts.obs_grid) store_obs(sw, board, g, N, ts.obs_grid + (size_t)b * N * g.n);
   if (ts.obs_step_count && lane == 0) ts.obs_step_count[b] = step_count;
 }
 
-__device__ __forceinline__ void write_extras(const uint32_t *board, const Geo &g, int N, int b,
-                                             int lane, const AgentRegs &ag,
+template <int LPB>
+__device__ __forceinline__ void write_extras(const SubWave<LPB> &sw, const uint32_t *board,
+                                             const Geo &g, int N, int b, const AgentRegs &ag,
                                              const TimestepPtrs &ts) {
+  const int lane = sw.l;
   const bool connected = lane < N && ag.r == ag.tr && ag.c == ag.tc;
-  const int conn = __popcll(__ballot(connected));
-  const int plen = ts.total_path_length ? count_path_cells(board, g, lane) : 0;
+  const int conn = __popcll(sw.ballot(connected));
+  const int plen = ts.total_path_length ? count_path_cells(sw, board, g) : 0;
   if (lane == 0) {
     if (ts.num_connections) ts.num_connections[b] = conn;
     if (ts.ratio_connections) ts.ratio_connections[b] = __fdiv_rn((float)conn, (float)N);
@@ -185,16 +198,18 @@ __device__ __forceinline__ void write_extras(const uint32_t *board, const Geo &g
 // ---------------------------------------------------------------------------------------------
 struct StepResult {
   bool was_connected, connected, done;  // per agent lane
-  bool last;                            // wave-uniform: all done or time limit reached
+  bool last;                            // per env (uniform in the sub-wave): all done or time limit
   uint32_t bits;                        // action mask of the stepped state
 };
 
 // _step_agent: move iff the action is not NOOP, the destination is in bounds and empty or the
 // agent's own target, and the agent is not connected yet.  Only an EMPTY cell can be contested
 // (a target cell admits its owner alone): max-join through one ds_max_u32, losers stay.
-__device__ __forceinline__ StepResult env_step_core(uint32_t *board, const Geo &g, int N, int lane,
-                                                    AgentRegs &ag, int &step_count, int act,
-                                                    int time_limit) {
+template <int LPB>
+__device__ __forceinline__ StepResult env_step_core(const SubWave<LPB> &sw, uint32_t *board,
+                                                    const Geo &g, int N, AgentRegs &ag,
+                                                    int &step_count, int act, int time_limit) {
+  const int lane = sw.l;
   const bool is_agent = lane < N;
   const uint32_t head = 3u * (uint32_t)lane + 2u;
   StepResult res;
@@ -221,7 +236,7 @@ __device__ __forceinline__ StepResult env_step_core(uint32_t *board, const Geo &
   res.connected = is_agent && ag.r == ag.tr && ag.c == ag.tc;
   res.bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
   res.done = res.connected || (res.bits >> 1) == 0u;  // connected_or_blocked
-  const bool all_done = __ballot(is_agent && !res.done) == 0ull;
+  const bool all_done = sw.ballot(is_agent && !res.done) == 0ull;
   res.last = all_done || step_count >= time_limit;
   return res;
 }
@@ -234,14 +249,18 @@ __device__ __forceinline__ float dense_reward(const StepResult &r, const rbg_env
 
 // Generator -> State in LDS/registers only: runs the walk for `key_in` (the generator's
 // argument), leaves the training grid in LDS, fills the agent registers, returns State.key.
-__device__ __forceinline__ Key2 regenerate(uint32_t *board, uint32_t *W, const Geo &g, int N,
-                                           int lane, Key2 key_in, AgentRegs &ag) {
-  const SubWave<64> sw(lane);
+template <int LPB>
+__device__ __forceinline__ Key2 regenerate(const SubWave<LPB> &sw, uint32_t *board, uint32_t *W,
+                                           const Geo &g, int N, Key2 key_in, AgentRegs &ag) {
   Key2 key, unused;
   split2_lanes(sw, key_in, key, unused);
   Walker w;
-  prw_walk_full(sw, board, W, g, N, key, w);
-  board_to_training(board, g, lane);
+  if constexpr (LPB == kWaveSize) {
+    prw_walk_full(sw, board, W, g, N, key, w);
+  } else {
+    prw_walk_impl<LPB, true>(sw, board, W, g, N, key, w);  // the host guarantees 2N + 2 <= LPB
+  }
+  board_to_training(sw, board, g);
   ag.r0 = w.r0; ag.c0 = w.c0;
   ag.tr = w.r;  ag.tc = w.c;
   ag.r = w.r0;  ag.c = w.c0;
@@ -249,10 +268,12 @@ __device__ __forceinline__ Key2 regenerate(uint32_t *board, uint32_t *W, const G
 }
 
 // State (LDS board + registers) -> HBM
-__device__ __forceinline__ void store_state(const uint32_t *board, const Geo &g, int N, int b,
-                                            int lane, const AgentRegs &ag, int step_count,
-                                            Key2 key, const StatePtrs &out) {
-  store_grid<64, false>(board, g, lane, out.grid + (size_t)b * g.n);
+template <int LPB>
+__device__ __forceinline__ void store_state(const SubWave<LPB> &sw, const uint32_t *board,
+                                            const Geo &g, int N, int b, const AgentRegs &ag,
+                                            int step_count, Key2 key, const StatePtrs &out) {
+  const int lane = sw.l;
+  store_grid<LPB, false>(board, g, lane, out.grid + (size_t)b * g.n);
   store_agents(out, b, N, lane, ag, true);
   if (lane == 0) {
     out.step_count[b] = step_count;
@@ -261,10 +282,12 @@ __device__ __forceinline__ void store_state(const uint32_t *board, const Geo &g,
 }
 
 // HBM -> State (LDS board + registers)
-__device__ __forceinline__ void load_state(uint32_t *board, const Geo &g, int N, int b, int lane,
-                                           const StatePtrs &in, AgentRegs &ag, int &step_count,
-                                           Key2 &key) {
-  load_grid(board, g, lane, in.grid + (size_t)b * g.n);
+template <int LPB>
+__device__ __forceinline__ void load_state(const SubWave<LPB> &sw, uint32_t *board, const Geo &g,
+                                           int N, int b, const StatePtrs &in, AgentRegs &ag,
+                                           int &step_count, Key2 &key) {
+  const int lane = sw.l;
+  load_grid(sw, board, g, in.grid + (size_t)b * g.n);
   if (lane < N) {
     const size_t o = ((size_t)b * N + lane) * 2;
     const int2 s = *reinterpret_cast<const int2 *>(&in.start[o]);
@@ -291,23 +314,25 @@ __device__ __forceinline__ void write_restart(int N, int b, int lane, const Time
 }
 
 // reward/discount/step_type of a stepped timestep
-__device__ __forceinline__ void write_step_outcome(const StepResult &res, const rbg_env_params &p,
-                                                   int N, int b, int lane,
+template <int LPB>
+__device__ __forceinline__ void write_step_outcome(const SubWave<LPB> &sw, const StepResult &res,
+                                                   const rbg_env_params &p, int N, int b,
                                                    const TimestepPtrs &ts) {
+  const int lane = sw.l;
   const float reward = dense_reward(res, p);
   const bool alive = !(res.last || res.done);
   if (lane < N) {
     if (ts.reward) ts.reward[(size_t)b * N + lane] = reward;
     if (ts.discount) ts.discount[(size_t)b * N + lane] = alive ? 1.0f : 0.0f;
   }
-  if (ts.reward_total) {  // MultiToSingleWrapper: float32 sum in agent order (wave-uniform branch)
+  if (ts.reward_total) {  // MultiToSingleWrapper: float32 sum in agent order (uniform branch)
     float total = 0.0f;
     for (int i = 0; i < N; ++i)
-      total = __fadd_rn(total, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(reward), i)));
+      total = __fadd_rn(total, __uint_as_float(sw.bcast(__float_as_uint(reward), i)));
     if (lane == 0) ts.reward_total[b] = total;
   }
   if (ts.discount_max) {
-    const bool any_alive = __ballot(lane < N && alive) != 0ull;
+    const bool any_alive = sw.ballot(lane < N && alive) != 0ull;
     if (lane == 0) ts.discount_max[b] = any_alive ? 1.0f : 0.0f;
   }
   if (lane == 0 && ts.step_type) ts.step_type[b] = res.last ? 2 : 1;
