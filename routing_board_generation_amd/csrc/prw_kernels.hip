@@ -322,32 +322,34 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   write_observation(sw, board, g, N, b, ag, step_count, a.ts);
 }
 
-// Side-stream producer of the stash: for every env whose entry is not the one its running
-// episode will need (tag != refill_key), generate G(split(refill_key)[0]) and publish it.
+// Producer of the stash: for every env whose entry is not the one its running episode will need
+// (tag != refill_key), generate G(split(refill_key)[0]) and publish it.  One env per sub-wave
+// (two per wave at 16x16/10); sub-waves with nothing to do retire at once.
 struct RefillArgs {
   int B, N;
   Geo g;
   StashPtrs stash;
 };
 
+template <int LPB>
 __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
-  const int lane = threadIdx.x & (kWaveSize - 1);
-  const SubWave<64> sw(lane);
+  constexpr int kSubs = SubWave<LPB>::kSubs;
+  const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x * kWavesPerBlock + wib;
+  const int b = (blockIdx.x * kWavesPerBlock + wib) * kSubs + sw.h;
   if (b >= a.B) return;
   const uint2 want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
   const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
-  if (want.x == have.x && want.y == have.y) return;  // wave-uniform: nothing to do for this env
-  uint32_t *board = g_lds + wib * slab_words<64>(a.g);
-  uint32_t *W = board + board_words(a.g);
+  if (want.x == have.x && want.y == have.y) return;  // nothing to do for this env
   const Geo g = a.g;
+  uint32_t *board = g_lds + (wib * kSubs + sw.h) * slab_words<LPB>(g);
+  uint32_t *W = board + board_words(g);
   AgentRegs ag = {0, 0, 0, 0, 0, 0};
   Key2 key = {want.x, want.y}, rk, unused;
   split2_lanes(sw, key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
   const Key2 next_key = regenerate(sw, board, W, g, a.N, rk, ag);
   store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
-  if (lane == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
+  if (sw.l == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -378,18 +380,27 @@ struct RolloutArgs {
   int tick, ready_delay;
 };
 
-// (4 waves per SIMD = one launch of 4096 envs resident at once: keep the VGPR budget at 128)
-__global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArgs a) {
-  const int lane = threadIdx.x & (kWaveSize - 1);
-  const SubWave<64> sw(lane);
+// One env per sub-wave of LPB lanes (the host picks the smallest LPB that holds the walk's 2N + 2
+// Threefry slots, like the generator): at 16x16/10 a wave steps two envs with one instruction
+// stream.  Per-env values (step_count, keys, counters) live in VGPRs, uniform inside the sub-wave;
+// an env that finishes an episode regenerates under its sub-wave's exec mask while the other
+// lanes of the wave wait -- every cross-lane operation of the env and walk code stays inside a
+// sub-wave, so that divergence is legal.
+// (LPB 64: 4 waves per SIMD = one launch of 4096 envs resident at once, VGPR budget 128.)
+template <int LPB>
+__global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_rollout_kernel(
+    RolloutArgs a) {
+  constexpr int kSubs = SubWave<LPB>::kSubs;
+  const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
+  const int l = sw.l;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x * kWavesPerBlock + wib;
-  if (b >= a.B) return;
-  uint32_t *board = g_lds + wib * slab_words<64>(a.g);
-  uint32_t *W = board + board_words(a.g);
+  const int b = (blockIdx.x * kWavesPerBlock + wib) * kSubs + sw.h;
+  if (b >= a.B) return;  // per sub-wave: the rest of the wave carries on
   const Geo g = a.g;
+  uint32_t *board = g_lds + (wib * kSubs + sw.h) * slab_words<LPB>(g);
+  uint32_t *W = board + board_words(g);
   const int N = a.N;
-  const bool is_agent = lane < N;
+  const bool is_agent = l < N;
   AgentRegs ag = {0, 0, 0, 0, 0, 0};
   int step_count;
   Key2 key, pk;
@@ -399,21 +410,21 @@ __global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArg
 
   int episodes = 0, conn_made = 0, pen_steps = 0, fin_conn = 0, fin_plen = 0;
   bool used_stash = false;
-  uint32_t bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
+  uint32_t bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
   for (int s = 0; s < a.n_steps; ++s) {
-    const int act = random_policy_action(pk, a.t0 + (uint32_t)s, (uint32_t)lane, bits);
+    const int act = random_policy_action(pk, a.t0 + (uint32_t)s, (uint32_t)l, bits);
     const StepResult res = env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit);
     bits = res.bits;
-    conn_made += __popcll(__ballot(!res.was_connected && res.connected));
-    pen_steps += __popcll(__ballot(is_agent && !res.was_connected));
+    conn_made += __popcll(sw.ballot(!res.was_connected && res.connected));
+    pen_steps += __popcll(sw.ballot(is_agent && !res.was_connected));
     const bool final_step = s == a.n_steps - 1;
     if (final_step) {
       write_step_outcome(sw, res, a.p, N, b, a.ts);
       write_extras(sw, board, g, N, b, ag, a.ts);
     }
-    if (res.last) {
+    if (res.last) {  // per env
       episodes += 1;
-      fin_conn += __popcll(__ballot(res.connected));
+      fin_conn += __popcll(sw.ballot(res.connected));
       if (a.stats.final_path_length) fin_plen += count_path_cells(sw, board, g);
       if (a.p.auto_reset) {
         bool hit = false;
@@ -424,21 +435,21 @@ __global__ __launch_bounds__(kBlock, 4) void connector_rollout_kernel(RolloutArg
         if (hit) {
           load_state(sw, board, g, N, b, a.stash.next, ag, step_count, key);
           used_stash = true;  // the entry is consumed; later resets of this launch walk inline
-          if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
+          if (a.stash.hits && l == 0) a.stash.hits[b] += 1;
         } else {
           Key2 rk, unused;
           split2_lanes(sw, key, rk, unused);
           key = regenerate(sw, board, W, g, N, rk, ag);
         }
         step_count = 0;
-        request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
-        bits = is_agent ? action_mask_bits(board, g, ag, lane) : 1u;
+        request_refill(a.stash, b, l, key, a.tick + a.ready_delay);
+        bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
       }
     }
   }
   store_state(sw, board, g, N, b, ag, step_count, key, a.out);
   write_observation(sw, board, g, N, b, ag, step_count, a.ts);
-  if (lane == 0) {
+  if (l == 0) {
     if (a.stats.episodes) a.stats.episodes[b] = episodes;
     if (a.stats.connections_made) a.stats.connections_made[b] = conn_made;
     if (a.stats.unconnected_agent_steps) a.stats.unconnected_agent_steps[b] = pen_steps;
@@ -784,14 +795,24 @@ int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream) 
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_stash_refill: B < 0");
   RefillArgs a;
   memset(&a, 0, sizeof(a));
-  if (int rc = make_geo(m, N, &a.g)) return rc;
+  const int lpb = (m >= 2 && m <= kMaxM && N >= 1 && N <= kMaxN) ? pick_lpb(m, N) : kWaveSize;
+  if (int rc = make_geo(m, N, &a.g, -1, lpb)) return rc;
   if (B == 0) return 0;
   if (!stash) return fail(RBG_E_NULL, "rbg_stash_refill: NULL stash");
   if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_stash_refill")) return rc;
   a.B = B; a.N = N;
-  hipLaunchKernelGGL(stash_refill_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
-                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  const int envs_per_block = kWavesPerBlock * (kWaveSize / lpb);
+  const dim3 grid((B + envs_per_block - 1) / envs_per_block), block(kBlock);
+  const size_t lds = lds_bytes(a.g, lpb);
+  hipStream_t st = (hipStream_t)stream;
+  if (lpb == 16) {
+    hipLaunchKernelGGL(stash_refill_kernel<16>, grid, block, lds, st, a);
+  } else if (lpb == 32) {
+    hipLaunchKernelGGL(stash_refill_kernel<32>, grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL(stash_refill_kernel<64>, grid, block, lds, st, a);
+  }
   return check_hip(hipGetLastError(), "rbg_stash_refill");
 }
 
@@ -849,7 +870,8 @@ int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_i
   if (params->time_limit < 1) return fail(RBG_E_PARAM, "rbg_connector_rollout: time_limit < 1");
   RolloutArgs a;
   memset(&a, 0, sizeof(a));
-  if (int rc = make_geo(m, N, &a.g)) return rc;
+  const int lpb = (m >= 2 && m <= kMaxM && N >= 1 && N <= kMaxN) ? pick_lpb(m, N) : kWaveSize;
+  if (int rc = make_geo(m, N, &a.g, -1, lpb)) return rc;
   if (B == 0) return 0;
   if (!policy_keys) return fail(RBG_E_NULL, "rbg_connector_rollout: NULL policy_keys");
   if (!state_complete(state_in) || !state_complete(state_out))
@@ -870,8 +892,17 @@ int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_i
     if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_connector_rollout_prefetch")) return rc;
   a.tick = tick; a.ready_delay = ready_delay;
-  hipLaunchKernelGGL(connector_rollout_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
-                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  const int envs_per_block = kWavesPerBlock * (kWaveSize / lpb);
+  const dim3 grid((B + envs_per_block - 1) / envs_per_block), block(kBlock);
+  const size_t lds = lds_bytes(a.g, lpb);
+  hipStream_t st = (hipStream_t)stream;
+  if (lpb == 16) {
+    hipLaunchKernelGGL(connector_rollout_kernel<16>, grid, block, lds, st, a);
+  } else if (lpb == 32) {
+    hipLaunchKernelGGL(connector_rollout_kernel<32>, grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL(connector_rollout_kernel<64>, grid, block, lds, st, a);
+  }
   return check_hip(hipGetLastError(), "rbg_connector_rollout");
 }
 
