@@ -100,12 +100,16 @@ __device__ __forceinline__ void store_obs(const SubWave<LPB> &sw, const uint32_t
 template <int LPB>
 __device__ __forceinline__ int count_path_cells(const SubWave<LPB> &sw, const uint32_t *board,
                                                 const Geo &g) {
+  // one sub-wave ballot + popcount per pass instead of a lane-to-lane reduction (six dependent
+  // ds_bpermute round trips); the trip count is uniform, lanes past the end contribute 0
   int cnt = 0;
-  for (int idx = sw.l; idx < g.n; idx += LPB) {
+  for (int base = 0; base < g.n; base += LPB) {
+    const int idx = base + sw.l;
     const int r = div_m(g, idx);
-    cnt += (int)(board[pad_index(g, r, idx - r * g.m)] % 3u == 1u);
+    const bool path = idx < g.n && board[pad_index(g, r, idx - r * g.m)] % 3u == 1u;
+    cnt += __popcll(sw.ballot(path));
   }
-  return sw.sum_i32(cnt);
+  return cnt;
 }
 
 struct TimestepPtrs {
