@@ -11,21 +11,32 @@
 
 namespace rbg {
 
-// HBM int32 grid -> padded LDS board
+// HBM int32 grid -> padded LDS board.  The first pass of global loads is issued before the wall
+// fill, so that their latency runs under it.
 template <int LPB>
 __device__ __forceinline__ void load_grid(const SubWave<LPB> &sw, uint32_t *board, const Geo &g,
                                           const int32_t *__restrict__ in) {
   const int lane = sw.l;
-  for (int w = lane; w < g.words; w += LPB) board[w] = kWall;
-  wave_lds_fence();
   if ((g.m & 3) == 0) {
-    for (int idx = lane * 4; idx < g.n; idx += LPB * 4) {
+    const int idx0 = lane * 4;
+    int4 v0 = make_int4(0, 0, 0, 0);
+    if (idx0 < g.n) v0 = *reinterpret_cast<const int4 *>(&in[idx0]);
+    for (int w = lane; w < g.words; w += LPB) board[w] = kWall;
+    wave_lds_fence();
+    if (idx0 < g.n) {
+      const int r = div_m(g, idx0);
+      *reinterpret_cast<uint4 *>(&board[pad_index(g, r, idx0 - r * g.m)]) =
+          make_uint4((uint32_t)v0.x, (uint32_t)v0.y, (uint32_t)v0.z, (uint32_t)v0.w);
+    }
+    for (int idx = idx0 + LPB * 4; idx < g.n; idx += LPB * 4) {
       const int r = div_m(g, idx);
       const int4 v = *reinterpret_cast<const int4 *>(&in[idx]);
       *reinterpret_cast<uint4 *>(&board[pad_index(g, r, idx - r * g.m)]) =
           make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
     }
   } else {
+    for (int w = lane; w < g.words; w += LPB) board[w] = kWall;
+    wave_lds_fence();
     for (int idx = lane; idx < g.n; idx += LPB) {
       const int r = div_m(g, idx);
       board[pad_index(g, r, idx - r * g.m)] = (uint32_t)in[idx];
@@ -291,7 +302,7 @@ __device__ __forceinline__ void load_state(const SubWave<LPB> &sw, uint32_t *boa
                                            int N, int b, const StatePtrs &in, AgentRegs &ag,
                                            int &step_count, Key2 &key) {
   const int lane = sw.l;
-  load_grid(sw, board, g, in.grid + (size_t)b * g.n);
+  // the small loads first: they are in flight while the grid is fetched and the walls are filled
   if (lane < N) {
     const size_t o = ((size_t)b * N + lane) * 2;
     const int2 s = *reinterpret_cast<const int2 *>(&in.start[o]);
@@ -300,8 +311,10 @@ __device__ __forceinline__ void load_state(const SubWave<LPB> &sw, uint32_t *boa
     ag.r0 = s.x; ag.c0 = s.y; ag.tr = t.x; ag.tc = t.y; ag.r = p.x; ag.c = p.y;
   }
   step_count = in.step_count[b];
-  key.a = in.key[2 * (size_t)b];
-  key.b = in.key[2 * (size_t)b + 1];
+  const uint2 k = *reinterpret_cast<const uint2 *>(&in.key[2 * (size_t)b]);
+  key.a = k.x;
+  key.b = k.y;
+  load_grid(sw, board, g, in.grid + (size_t)b * g.n);
 }
 
 // reward/discount/step_type of a restart timestep
