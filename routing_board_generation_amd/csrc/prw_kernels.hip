@@ -244,7 +244,7 @@ struct EnvArgs {
   int tick, ready_delay;
 };
 
-// after a (re)start: ask the side-stream refill for the entry of the new episode's key
+// after a (re)start: ask the next refill for the entry of the new episode's key
 __device__ __forceinline__ void request_refill(const StashPtrs &st, int b, int lane, Key2 key,
                                                int ready_at) {
   if (st.refill_key && lane == 0) {
@@ -272,7 +272,8 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     const Key2 key = regenerate(sw, board, W, g, N, kin, ag);
     store_state(sw, board, g, N, b, ag, 0, key, a.out);
     request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
-    write_observation(sw, board, g, N, b, ag, 0, a.ts);
+    write_observation(sw, board, g, N, b, ag, 0, a.ts,
+                      lane < N ? action_mask_bits(board, g, ag, lane) : 1u);
     write_extras(sw, board, g, N, b, ag, a.ts);
     write_restart(N, b, lane, a.ts);
     return;
@@ -283,7 +284,8 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   load_state(sw, board, g, N, b, a.in, ag, step_count, key);
 
   if (a.mode == 1) {  // ---- observe an existing state (restart timestep) ----------------------
-    write_observation(sw, board, g, N, b, ag, step_count, a.ts);
+    write_observation(sw, board, g, N, b, ag, step_count, a.ts,
+                      lane < N ? action_mask_bits(board, g, ag, lane) : 1u);
     write_extras(sw, board, g, N, b, ag, a.ts);
     write_restart(N, b, lane, a.ts);
     return;
@@ -294,14 +296,15 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   const StepResult res = env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit);
   write_step_outcome(sw, res, a.p, N, b, a.ts);
   write_extras(sw, board, g, N, b, ag, a.ts);
+  uint32_t bits = res.bits;  // action mask of the state that is observed next
 
   if (res.last && a.p.auto_reset) {
     // VmapAutoResetWrapper._auto_reset: key, _ = split(state.key); state, ts = reset(key);
     // only the observation of the terminal timestep is replaced.
-    // With a stash the new episode's State was generated ahead of time on a side stream
-    // (stash_refill_kernel) and is only copied here; the entry is valid iff it was generated for
-    // exactly this episode's key and the refill that wrote it is known to have completed
-    // (ready_at: synchronised through stream events on the host, never through in-kernel flags).
+    // With a stash the new episode's State was generated ahead of time (stash_refill_kernel)
+    // and is only copied here; the entry is valid iff it was generated for exactly this
+    // episode's key and the refill that wrote it is known to have completed (ready_at: ordered
+    // by the host through the stream, never through in-kernel flags).
     bool hit = false;
     if (a.stash.tag) {
       const uint2 tag = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
@@ -317,9 +320,10 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     }
     step_count = 0;
     request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
+    bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
   }
   store_state(sw, board, g, N, b, ag, step_count, key, a.out);
-  write_observation(sw, board, g, N, b, ag, step_count, a.ts);
+  write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
 }
 
 // Producer of the stash: for every env whose entry is not the one its running episode will need
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_
     }
   }
   store_state(sw, board, g, N, b, ag, step_count, key, a.out);
-  write_observation(sw, board, g, N, b, ag, step_count, a.ts);
+  write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
   if (l == 0) {
     if (a.stats.episodes) a.stats.episodes[b] = episodes;
     if (a.stats.connections_made) a.stats.connections_made[b] = conn_made;

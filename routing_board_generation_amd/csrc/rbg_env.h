@@ -185,9 +185,9 @@ __device__ __forceinline__ void board_to_training(const SubWave<LPB> &sw, uint32
 template <int LPB>
 __device__ __forceinline__ void write_observation(const SubWave<LPB> &sw, const uint32_t *board,
                                                   const Geo &g, int N, int b, const AgentRegs &ag,
-                                                  int step_count, const TimestepPtrs &ts) {
+                                                  int step_count, const TimestepPtrs &ts,
+                                                  uint32_t bits) {  // action mask of (board, ag)
   const int lane = sw.l;
-  const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
   store_mask(ts, b, N, lane, bits);
   if (ts.obs_grid) store_obs(sw, board, g, N, ts.obs_grid + (size_t)b * N * g.n);
   if (ts.obs_step_count && lane == 0) ts.obs_step_count[b] = step_count;
