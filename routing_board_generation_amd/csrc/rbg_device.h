@@ -175,22 +175,6 @@ struct SubWave {
     return v;
   }
 
-  __device__ __forceinline__ int sum_i32(int v) const {
-#pragma unroll
-    for (int off = LPB / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-  }
-
-  // wave-uniform maximum of a value that is uniform inside each sub-wave
-  __device__ __forceinline__ int max_over_subs(int v) const {
-    int r = __builtin_amdgcn_readlane(v, 0);
-#pragma unroll
-    for (int s = 1; s < kSubs; ++s) {
-      const int t = __builtin_amdgcn_readlane(v, s * LPB);
-      r = t > r ? t : r;
-    }
-    return r;
-  }
 };
 
 // split(key) with the two Threefry blocks in sub-lanes 0 and 1 of ONE evaluation:

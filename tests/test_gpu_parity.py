@@ -535,7 +535,7 @@ def test_c_api_demo_program(oracle, tmp_path):
 # ------------------------------------------------------------------------------ prefetched resets
 @pytest.mark.parametrize("delay", [1, 4])
 def test_prefetched_auto_reset_matches_oracle(rbg, oracle, delay):
-    """VmapAutoResetWrapper(prefetch=True): next-episode States come from the side-stream stash;
+    """VmapAutoResetWrapper(prefetch=True): next-episode States come from the stash;
     every state and timestep must equal the inline path (= the oracle), and the stash must
     actually be hit once it is warm."""
     from routing_board_generation_amd import ops
