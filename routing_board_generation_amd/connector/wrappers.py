@@ -44,8 +44,8 @@ class VmapAutoResetWrapper(_Wrapper):
     the same kernel launch from split(state.key)[0], keeping reward/discount/step_type/extras of
     the terminal step and replacing only the observation."""
 
-    def __init__(self, env, prefetch: bool = False, prefetch_delay: int = 16, donate=None):
-        """prefetch=True generates every env's NEXT episode ahead of time
+    def __init__(self, env, prefetch: bool = True, prefetch_delay: int = 16, donate=None):
+        """prefetch=True (default) generates every env's NEXT episode ahead of time
         (include/rbg_prw.h::rbg_stash): one refill launch per `prefetch_delay` steps walks for all
         the envs that restarted since the last one, instead of every step launch waiting for the
         walks of its own finished envs; results are identical with and without it.

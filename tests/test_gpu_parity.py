@@ -229,7 +229,7 @@ def test_connector_rollout_matches_oracle(rbg, oracle, torch_mod, m, N, B, steps
 
     env = rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), time_limit=20)
     if auto_reset:
-        env = rbg.VmapAutoResetWrapper(env)
+        env = rbg.VmapAutoResetWrapper(env, prefetch=False)  # the fused (inline) reset path
     keys = _keys(rbg, 4, B)
     akeys = _keys(rbg, 1, B)
     state, ts = env.reset(keys)
