@@ -786,3 +786,18 @@ def test_many_boards_match_oracle(rbg, oracle, torch_mod, m, N, log2b):
         assert (to_np(out["target"]) == st["target"]).all()
         assert (to_np(out["iters"]) == iters).all()
         assert (to_np(out["key_out"]) == st["key"]).all()
+
+
+def test_random_agent_loop_example_runs():
+    """examples/random_agent_loop.py: the reference's acting loop on the drop-in classes."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output(
+        [sys.executable, os.path.join(root, "examples", "random_agent_loop.py"), "--epochs", "2",
+         "--batch-per-gpu", "512", "--n-steps", "60"], text=True, cwd=root, timeout=600)
+    lines = [ln for ln in out.splitlines() if ln.startswith("epoch")]
+    assert len(lines) == 2 and "episodes" in lines[1], out
+    assert int(lines[1].split(" GPU(s), ")[1].split(" episodes")[0]) > 256, out
