@@ -3,7 +3,7 @@
 // Device code lives in the headers next to this file:
 //   rbg_device.h   jax's Threefry-2x32, sub-wave helpers, the padded LDS board
 //   rbg_walk.h     ParallelRandomWalk (one board per sub-wave of 16/32/64 lanes)
-//   rbg_env.h      Connector reset / step / observation pieces (one env per wavefront)
+//   rbg_env.h      Connector reset / step / observation pieces (one env per sub-wave)
 //   rbg_seqwalk.h  SequentialRandomWalk (one board per wavefront)
 // Common design:
 //   * a board lives in LDS as a "padded" image (2 wall rows above/below, 4 wall columns shared
