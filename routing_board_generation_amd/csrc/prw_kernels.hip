@@ -88,11 +88,7 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   if (sw.lane == 0) w.stamp[0] = (int32_t)probe_t0;
   RBG_STAMP(w, 1);
 #endif
-  if constexpr (LPB == kWaveSize) {
-    prw_walk_full(sw, board, W, g, a.N, key, w);
-  } else {
-    prw_walk_impl<LPB, true>(sw, board, W, g, a.N, key, w);
-  }
+  prw_walk(sw, board, W, g, a.N, key, w);
   if (!valid) return;
 
   const size_t gofs = (size_t)b * g.n;

@@ -270,11 +270,7 @@ __device__ __forceinline__ Key2 regenerate(const SubWave<LPB> &sw, uint32_t *boa
   Key2 key, unused;
   split2_lanes(sw, key_in, key, unused);
   Walker w;
-  if constexpr (LPB == kWaveSize) {
-    prw_walk_full(sw, board, W, g, N, key, w);
-  } else {
-    prw_walk_impl<LPB, true>(sw, board, W, g, N, key, w);  // the host guarantees 2N + 2 <= LPB
-  }
+  prw_walk(sw, board, W, g, N, key, w);
   board_to_training(sw, board, g);
   ag.r0 = w.r0; ag.c0 = w.c0;
   ag.tr = w.r;  ag.tc = w.c;

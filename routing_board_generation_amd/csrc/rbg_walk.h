@@ -187,10 +187,13 @@ struct PrngLanes {  // per-lane constants of the single-evaluation layout (2N + 
 // the chain key k that the split and chain slots of the NEXT evaluation start from.  Every lane
 // therefore finds the key of its role with one ds_read_b64 and nothing is broadcast through
 // readlanes.
+// Evaluation e of a round covers the virtual slots [e * LPB, (e + 1) * LPB): slot s = l + e * LPB.
+// One evaluation when 2N + 2 <= LPB; two when N <= LPB and 2N + 2 <= 2 * LPB (then every uniform
+// slot lies in evaluation 0, i.e. in its agent's own lane, and both chain slots in evaluation 1).
 template <int LPB>
-__device__ __forceinline__ PrngLanes<LPB> prng_lanes(int N, int l) {
+__device__ __forceinline__ PrngLanes<LPB> prng_lanes(int N, int l, int e = 0) {
   PrngLanes<LPB> p;
-  const int twoN = 2 * N, s = l, dump = 2 * LPB + 2 * l;  // this lane's own dump words
+  const int twoN = 2 * N, s = l + e * LPB, dump = 2 * LPB + 2 * l;  // this lane's own dump words
   p.r_uni = s < N;
   const bool r_split = !p.r_uni && s < twoN;
   const bool r_chain = s >= twoN && s < twoN + 2;
@@ -308,8 +311,10 @@ struct Walker {
 // still monotone in the agent id, which is all the max-join needs.  Heads and targets are
 // written once at the end from the positions kept in registers.
 //
-// kSingle: 2N + 2 <= LPB, one Threefry evaluation per iteration, software-pipelined.
-template <int LPB, bool kSingle>
+// kEvals: Threefry evaluations per iteration.  1: 2N + 2 <= LPB, software-pipelined; 2: N <= LPB and
+// 2N + 2 <= 2 * LPB, the first one pipelined like the single one and the second issued behind it;
+// 0: the generic loop of prng_round_multi (full-wave boards with N >= 32).
+template <int LPB, int kEvals>
 __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *board,
                                               uint32_t *W, const Geo &g, int N, Key2 key,
                                               Walker &w) {
@@ -360,10 +365,13 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
   // pipeline prologue: W <- split(k_0, N), kcur <- k_1; then u <- u(0), W <- split(k_1, N), ...
   const PrngLanes<LPB> pl = prng_lanes<LPB>(N, l);
   float u;  // 1 + uniform of this lane's agent for the coming iteration
-  if (kSingle) {
+  const PrngLanes<LPB> pl1 = prng_lanes<LPB>(N, l, 1);  // second evaluation (kEvals == 2)
+  if (kEvals >= 1) {
     prng_seed(W, N, l, kcur);
     (void)prng_round_single(W, pl);
+    if (kEvals == 2) (void)prng_round_single(W, pl1);
     u = prng_round_single(W, pl);
+    if (kEvals == 2) (void)prng_round_single(W, pl1);
   } else {
     (void)prng_round_multi(W, N, sw.lane, kcur);
     u = prng_round_multi(W, N, sw.lane, kcur);
@@ -383,7 +391,9 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
   for (int t = 0; t < max_iters; ++t) {
     // randomness of the NEXT iteration is independent of the board: its LDS read goes first ...
     uint2 kk = make_uint2(0u, 0u);
-    if (kSingle) kk = prng_issue<LPB>(W, pl);
+    uint2 kk1 = make_uint2(0u, 0u);
+    if (kEvals >= 1) kk = prng_issue<LPB>(W, pl);
+    if (kEvals == 2) kk1 = prng_issue<LPB>(W, pl1);
     // ---- _available_cells for [up, down, left, right] (:293-374) -------------------------
     // candidate q is available iff it is empty and touches no cell of this wire other than the
     // head itself ("doubling back" counts the head once, so the other three must be foreign).
@@ -400,7 +410,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     TfState tf = {0u, 0u, 0u, 0u, 0u};
     float u_next = 0.0f;
     __builtin_amdgcn_sched_barrier(0);
-    if (kSingle) {
+    if (kEvals >= 1) {
       tf = prng_first<LPB>(pl, kk);
       // pin the half-finished state here: without it the optimiser sinks these rounds below
       // the loop's exit test, i.e. out of the stencil's latency shadow
@@ -447,7 +457,11 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     const uint32_t after = board[Q];
     __builtin_amdgcn_sched_barrier(0);
     // the remaining Threefry rounds hide the ds_max + read-back round trip
-    if (kSingle) u_next = prng_second<LPB>(W, pl, tf);
+    if (kEvals >= 1) u_next = prng_second<LPB>(W, pl, tf);
+    if (kEvals == 2) {  // the slots past LPB: rest of split(k, N) and the chain
+      const TfState tf1 = prng_first<LPB>(pl1, kk1);
+      (void)prng_second<LPB>(W, pl1, tf1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const bool won = after == wire;  // never true for a wall; a no-op for a non-moving agent
     w.P = won ? Q : P;
@@ -465,13 +479,23 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
   wave_lds_fence();
 }
 
-// Full-wave board (LPB = 64): pick the pipeline by N.
-__device__ __forceinline__ void prw_walk_full(const SubWave<64> &sw, uint32_t *board, uint32_t *W,
-                                              const Geo &g, int N, Key2 key, Walker &w) {
-  if (2 * N + 2 <= kWaveSize) {
-    prw_walk_impl<64, true>(sw, board, W, g, N, key, w);
-  } else {
-    prw_walk_impl<64, false>(sw, board, W, g, N, key, w);
+// The walk with the Threefry pipeline that fits (N, LPB) -- a wave-uniform choice.  The host picks
+// the smallest LPB with 2N + 2 <= LPB; only full-wave boards need more than one evaluation.
+// (Two evaluations on narrower sub-waves -- four 16x16/10 boards per wave, two 32x32/20 -- are
+// bit-exact too but measured slower at every batch size: 51.6 vs 36 us and 230 vs 244 boards/us
+// for 16x16/10, 136 vs 98 us for 32x32/20; fewer, longer waves lose more to the slowest board of
+// the wave than they save in instructions.)
+template <int LPB>
+__device__ __forceinline__ void prw_walk(const SubWave<LPB> &sw, uint32_t *board, uint32_t *W,
+                                         const Geo &g, int N, Key2 key, Walker &w) {
+  if (2 * N + 2 <= LPB) {
+    prw_walk_impl<LPB, 1>(sw, board, W, g, N, key, w);
+  } else if constexpr (LPB == kWaveSize) {
+    if (2 * N + 2 <= 2 * LPB) {
+      prw_walk_impl<LPB, 2>(sw, board, W, g, N, key, w);  // 32 <= N <= 63
+    } else {
+      prw_walk_impl<LPB, 0>(sw, board, W, g, N, key, w);  // N = 64: three evaluations
+    }
   }
 }
 
