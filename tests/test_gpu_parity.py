@@ -761,6 +761,7 @@ SWEEP = [  # (m, N, log2 B at scale 1): all three sub-wave widths, both Threefry
     # register / LDS variants of the start-cell shuffle, odd and even cell counts
     (16, 10, 17), (8, 5, 15), (10, 5, 15), (12, 7, 14), (16, 15, 13), (32, 20, 12), (22, 12, 12),
     (23, 12, 12), (40, 15, 10), (9, 7, 13), (5, 6, 13), (20, 31, 11), (20, 32, 10),
+    (20, 40, 10), (32, 33, 9), (40, 63, 8), (16, 64, 8),
 ]
 
 
