@@ -206,6 +206,10 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="batches of 4096 boards timed for cpu_baseline (0 = skip; default: "
                          "threads/4, i.e. ~20 core-seconds of CPU work)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the K generator launches with three batches in flight on "
+                         "three streams (off by default so that the rocprofv3 kernel statistics "
+                         "of the default command describe lone launches only)")
     ap.add_argument("--all-configs", action="store_true",
                     help="measure every BASELINE.json config (GPU + CPU port) and print a JSON "
                          "list instead of the driver's line (profiles/*_configs.json)")
@@ -289,39 +293,41 @@ def main() -> None:
                 "note": "latency-bound walk (serial dependent iterations per board): HBM fraction "
                         "reported for the record; see DESIGN.md"}
 
-    # The same K launches with three batches in flight (three streams, three output sets): a lone
-    # launch of 4096 boards ends on the serial walk of its longest board while most SIMDs idle,
-    # so independent batches overlap almost for free.  Reported next to `value`, never as it.
-    n_streams = 3  # + the default stream: within the 4 hardware queues HIP multiplexes streams onto
-    p_streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-    p_outs = [ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_train=True,
-                               want_state=True, want_iters=True) for _ in range(n_streams)]
+    pipelined = None
+    if args.pipelined:
+        # The same K launches with three batches in flight (three streams, three output sets): a lone
+        # launch of 4096 boards ends on the serial walk of its longest board while most SIMDs idle,
+        # so independent batches overlap almost for free.  Reported next to `value`, never as it.
+        n_streams = 3  # + the default stream: within the 4 hardware queues HIP multiplexes streams onto
+        p_streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        p_outs = [ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_train=True,
+                                   want_state=True, want_iters=True) for _ in range(n_streams)]
 
-    import ctypes as C
-    p_lib = rbg._native.lib()
-    p_args = [(keys.data_ptr(), B, m, N, 1, None, o["train_grid"].data_ptr(), o["start"].data_ptr(),
-               o["target"].data_ptr(), o["position"].data_ptr(), o["step_count"].data_ptr(),
-               o["key_out"].data_ptr(), o["iters"].data_ptr(), C.c_void_p(st.cuda_stream))
-              for o, st in zip(p_outs, p_streams)]  # the launch of ops.prw_generate, stream given
+        import ctypes as C
+        p_lib = rbg._native.lib()
+        p_args = [(keys.data_ptr(), B, m, N, 1, None, o["train_grid"].data_ptr(), o["start"].data_ptr(),
+                   o["target"].data_ptr(), o["position"].data_ptr(), o["step_count"].data_ptr(),
+                   o["key_out"].data_ptr(), o["iters"].data_ptr(), C.c_void_p(st.cuda_stream))
+                  for o, st in zip(p_outs, p_streams)]  # the launch of ops.prw_generate, stream given
 
-    def run_pipelined(k):
-        for i in range(k):
-            rc = p_lib.rbg_prw_generate(*p_args[i % n_streams])
-            if rc:
-                rbg._native.check(rc, "rbg_prw_generate")
+        def run_pipelined(k):
+            for i in range(k):
+                rc = p_lib.rbg_prw_generate(*p_args[i % n_streams])
+                if rc:
+                    rbg._native.check(rc, "rbg_prw_generate")
 
-    run_pipelined(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_pipelined(args.steps)
-    barrier()
-    pm = sharding.all_reduce_metrics({"boards": float(B * args.steps),
-                                      "elapsed_s": time.perf_counter() - t0}, device=dev)
-    pipelined = {"streams": n_streams, "value": pm["boards"] / pm["elapsed_s"], "unit": "boards/s",
-                 "ms_per_step": pm["elapsed_s"] / args.steps * 1e3,
-                 "note": "the same steps with three batches of 4096 in flight on three HIP streams "
-                         "(distinct output buffers); about the rate of one large batch"}
-    del p_outs
+        run_pipelined(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_pipelined(args.steps)
+        barrier()
+        pm = sharding.all_reduce_metrics({"boards": float(B * args.steps),
+                                          "elapsed_s": time.perf_counter() - t0}, device=dev)
+        pipelined = {"streams": n_streams, "value": pm["boards"] / pm["elapsed_s"], "unit": "boards/s",
+                     "ms_per_step": pm["elapsed_s"] / args.steps * 1e3,
+                     "note": "the same steps with three batches of 4096 in flight on three HIP streams "
+                             "(distinct output buffers); about the rate of one large batch"}
+        del p_outs
 
     # ---------------------------------------------------------------- secondary: env.step rollout
     # BASELINE configs[2] through the per-step API: every step = masked-uniform policy kernel +
