@@ -476,32 +476,52 @@ def main() -> None:
     # ---------------------------------------------------------------- secondary: fused rollout
     rollout = None
     if args.rollout_steps > 0:
-        st, _ = ops.connector_reset(keys, m, N)
-        stats = {k: torch.empty((B,), dtype=torch.int32, device=dev) for k in ops.ROLLOUT_STATS}
-        ops.connector_rollout(st, keys, 0, args.rollout_steps, state_out=st, stats=stats)
         launches = 10
-        re0, re1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
-        t2 = time.perf_counter()
-        re0.record()
-        for i in range(launches):
-            ops.connector_rollout(st, keys, (i + 1) * args.rollout_steps, args.rollout_steps,
-                                  state_out=st, stats=stats)
-        re1.record()
-        barrier()
-        r_elapsed = time.perf_counter() - t2
-        rm = sharding.all_reduce_metrics(
-            {"env_steps": float(B * args.rollout_steps * launches),
-             "episodes": float(stats["episodes"].sum().item()), "elapsed_s": r_elapsed}, device=dev)
-        rollout = {"metric": "env_steps_per_sec", "value": rm["env_steps"] / rm["elapsed_s"],
-                   "unit": "env-steps/s", "steps_per_launch": args.rollout_steps,
-                   "launches": launches, "auto_reset": True,
-                   "kernel": "connector_rollout_kernel",
-                   "kernel_avg_ms": re0.elapsed_time(re1) / launches,
-                   "episodes_per_launch": rm["episodes"],
-                   "note": "rbg_connector_rollout: random policy + step + fused auto-reset, env "
-                           "resident in LDS across steps; no per-step observation traffic, so not "
-                           "HBM-bound (state in/out once per launch)"}
+
+        def run_rollout(use_stash):
+            stats = {k: torch.empty((B,), dtype=torch.int32, device=dev) for k in ops.ROLLOUT_STATS}
+            ep = None
+            if use_stash:  # two slots per env, refilled behind every launch (EpochStash)
+                ep = ops.EpochStash(B, m, N, dev, every=1, serial=True, depth=2)
+                ep.before_launch()
+                st, _ = ops.connector_reset_prefetch(keys, m, N, ep.stash, ep.tick,
+                                                     ep.ready_delay())
+                ep.after_launch()
+            else:
+                st, _ = ops.connector_reset(keys, m, N)
+            for i in range(2):  # warm-up (the stash serves resets from the second launch on)
+                ops.connector_rollout(st, keys, i * args.rollout_steps, args.rollout_steps,
+                                      state_out=st, stats=stats, epochs=ep)
+            re0, re1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            t2 = time.perf_counter()
+            re0.record()
+            for i in range(launches):
+                ops.connector_rollout(st, keys, (i + 2) * args.rollout_steps, args.rollout_steps,
+                                      state_out=st, stats=stats, epochs=ep)
+            re1.record()
+            barrier()
+            r_elapsed = time.perf_counter() - t2
+            rm = sharding.all_reduce_metrics(
+                {"env_steps": float(B * args.rollout_steps * launches),
+                 "episodes": float(stats["episodes"].sum().item()), "elapsed_s": r_elapsed},
+                device=dev)
+            return (rm["env_steps"] / rm["elapsed_s"], re0.elapsed_time(re1) / launches,
+                    rm["episodes"])
+
+        v_stash, ms_stash, eps = run_rollout(True)
+        v_plain, ms_plain, _ = run_rollout(False)
+        rollout = {"metric": "env_steps_per_sec", "value": v_stash, "unit": "env-steps/s",
+                   "steps_per_launch": args.rollout_steps, "launches": launches,
+                   "auto_reset": True, "kernel": "connector_rollout_kernel + stash_refill_kernel",
+                   "launch_avg_ms": ms_stash, "episodes_per_launch": eps,
+                   "fused_resets": {"value": v_plain, "launch_avg_ms": ms_plain},
+                   "note": "rbg_connector_rollout_prefetch: random policy + step, env resident in "
+                           "LDS across steps, resets served from a two-slot next-episode stash "
+                           "that one refill launch per rollout launch keeps full "
+                           "(fused_resets: the walks inside the rollout launch instead); no "
+                           "per-step observation traffic, so not HBM-bound (state in/out once "
+                           "per launch)"}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample != 0:

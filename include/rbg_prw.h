@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 2
+#define RBG_ABI_VERSION 3
 
 #define RBG_E_NULL (-1)   /* a required pointer is NULL */
 #define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
@@ -168,26 +168,35 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  * the envs that restarted recently (a throughput-shaped batch of walks) instead of by every step
  * launch for its own few finished envs (a launch that lasts as long as its longest walk); the
  * step then copies 1.3 KB instead of walking.
- *   next        a full rbg_state for B envs: next[b] = reset(split(tag[b])[0])
- *   tag         uint32 [B][2]: the State.key next[b] was generated for (zero-initialised)
- *   ready_at    int32 [B]: first launch tick that may consume the entry (zero-initialised)
- *   refill_key  uint32 [B][2]: State.key of the running episode, i.e. the entry wanted next
+ *   depth       slots per env, 1 or 2; slot s of env b is row s * B + b of every array below
+ *   next        a full rbg_state of depth * B rows: next[r] = reset(split(tag[r])[0])
+ *   tag         uint32 [depth*B][2]: the State.key next[r] was generated for (zero-initialised)
+ *   ready_at    int32 [depth*B]: first launch tick that may consume the row (zero-initialised)
+ *   refill_key  uint32 [depth*B][2]: the State.key whose successor the row should hold next
  *   hits        int32 [B], nullable: resets served from the stash (diagnostics; caller zeroes)
  * Protocol (host-driven, kernel boundaries only -- no in-kernel cross-stream flags):
- *   every reset/step launch has a tick t = 0, 1, 2, ...  A launch that (re)starts env b writes
- *   refill_key[b] and ready_at[b] = t + ready_delay, where the caller guarantees that a refill
- *   launched after launch t has completed before launch t + ready_delay starts.  With the
- *   refill on the launches' own stream every K launches that is the next multiple of K (stream
- *   order, no events; what routing_board_generation_amd.ops.EpochStash does by default); with
- *   the refill on a side stream it takes a stream event.  An entry is consumed only if
- *   tick >= ready_at[b] and tag[b] == state.key[b]; otherwise the walk runs inline, so results
- *   never depend on timing. */
+ *   every reset/step launch has a tick t = 0, 1, 2, ...  A launch that (re)starts env b with
+ *   State.key k writes requests (refill_key, ready_at = t + ready_delay), where the caller
+ *   guarantees that a refill launched after launch t has completed before launch
+ *   t + ready_delay starts.  With the refill on the launches' own stream every K launches that
+ *   is the next multiple of K (stream order, no events; what
+ *   routing_board_generation_amd.ops.EpochStash does by default); with the refill on a side
+ *   stream it takes a stream event.  A row is consumed only if tick >= ready_at[r] and
+ *   tag[r] == state.key[b]; otherwise the walk runs inline, so results never depend on timing.
+ *   depth 1: the one row of env b is requested for k (the successor of the episode that starts).
+ *   depth 2: one row is reserved for k unless one already is, and the other -- the one just
+ *   consumed -- is requested for the key of the episode AFTER the next,
+ *   split(split(k)[0])[0]: every entry is then asked for a whole episode before it is needed,
+ *   which lets a launch of many steps (rbg_connector_rollout) serve all its resets from the
+ *   stash, also those of an env that finishes two episodes within it.  The number of walks is
+ *   the same as with depth 1; they only happen one episode earlier. */
 typedef struct rbg_stash {
   rbg_state next;
   uint32_t *tag;
   int32_t *ready_at;
   uint32_t *refill_key;
   int32_t *hits;
+  int32_t depth;
 } rbg_stash;
 
 /* rbg_connector_reset / rbg_connector_step with a stash (NULL stash = the plain calls). */
@@ -198,8 +207,8 @@ int rbg_connector_step_prefetch(int B, int m, int N, const rbg_state *state_in,
                                 const rbg_state *state_out, const int32_t *action,
                                 const rbg_env_params *params, const rbg_timestep *timestep,
                                 const rbg_stash *stash, int tick, int ready_delay, void *stream);
-/* Generate next[b] for every env with tag[b] != refill_key[b] (one wave per env; the others
- * exit at once). */
+/* Generate next[r] for every row with tag[r] != refill_key[r] (one sub-wave per row; the others
+ * retire at once). */
 int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream);
 
 /* Masked-uniform random policy over the legal set (defined by this project; stands in for

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
 HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
                "-std=c++17"]
 
@@ -44,7 +44,7 @@ class RolloutStats(C.Structure):
 
 class Stash(C.Structure):
     _fields_ = [("next", State), ("tag", C.c_void_p), ("ready_at", C.c_void_p),
-                ("refill_key", C.c_void_p), ("hits", C.c_void_p)]
+                ("refill_key", C.c_void_p), ("hits", C.c_void_p), ("depth", C.c_int32)]
 
 
 class EnvParams(C.Structure):

@@ -96,6 +96,7 @@ class Connector:
         self._donate = bool(donate)
         self._aggregate = False  # switched on by MultiToSingleWrapper
         self._sessions = {}  # (B, device, wrapper + env parameters) -> ops.ConnectorSession
+        self._rollout_epochs = {}  # (B, device) -> ops.EpochStash of random_rollout
 
     @property
     def unwrapped(self) -> "Connector":
@@ -201,10 +202,20 @@ class Connector:
             raise ValueError("random_rollout expects a batched state")
         if self._auto_reset and not isinstance(self._generator, ParallelRandomWalkGenerator):
             raise NotImplementedError("fused rollouts need the ParallelRandomWalkGenerator")
+        epochs = None
+        if self._auto_reset and self._prefetch_delay > 0:
+            # two-slot next-episode stash, refilled after every launch: also an env that finishes
+            # two episodes within the launch finds both successors ready
+            B, dev = state.grid.shape[0], state.grid.device
+            epochs = self._rollout_epochs.get((B, dev))
+            if epochs is None:
+                self._rollout_epochs.clear()
+                epochs = self._rollout_epochs[(B, dev)] = ops.EpochStash(
+                    B, self.grid_size, self.num_agents, dev, every=1, serial=True, depth=2)
         so, stats, ts = ops.connector_rollout(
             _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
             self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
-            auto_reset=self._auto_reset, want_timestep=want_timestep)
+            auto_reset=self._auto_reset, want_timestep=want_timestep, epochs=epochs)
         return _make_state(so, True), stats, (_make_timestep(ts, True) if ts is not None else None)
 
     def _generic_auto_reset(self, so, ts):

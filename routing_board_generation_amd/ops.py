@@ -270,23 +270,30 @@ def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
 
 
 # ------------------------------------------------------------------------------------- prefetch
-def alloc_stash(B: int, m: int, N: int, device) -> dict:
-    """Buffers of include/rbg_prw.h::rbg_stash (tag / ready_at / refill_key / hits zeroed)."""
-    return {"next": alloc_state(B, m, N, device),
-            "tag": torch.zeros((B, 2), dtype=torch.uint32, device=device),
-            "ready_at": torch.zeros((B,), dtype=torch.int32, device=device),
-            "refill_key": torch.zeros((B, 2), dtype=torch.uint32, device=device),
-            "hits": torch.zeros((B,), dtype=torch.int32, device=device)}
+def alloc_stash(B: int, m: int, N: int, device, depth: int = 1) -> dict:
+    """Buffers of include/rbg_prw.h::rbg_stash (tag / ready_at / refill_key / hits zeroed);
+    `depth` slots per env, slot s of env b in row s * B + b."""
+    if depth not in (1, 2):
+        raise ValueError("stash depth must be 1 or 2")
+    R = depth * B
+    return {"next": alloc_state(R, m, N, device),
+            "tag": torch.zeros((R, 2), dtype=torch.uint32, device=device),
+            "ready_at": torch.zeros((R,), dtype=torch.int32, device=device),
+            "refill_key": torch.zeros((R, 2), dtype=torch.uint32, device=device),
+            "hits": torch.zeros((B,), dtype=torch.int32, device=device),
+            "depth": depth}
 
 
 def _stash_struct(stash: dict, B: int, m: int, N: int) -> nat.Stash:
-    nxt = _state_struct(stash["next"], B, m, N)
-    _check(stash["tag"], torch.uint32, (B, 2), "stash.tag")
-    _check(stash["ready_at"], torch.int32, (B,), "stash.ready_at")
-    _check(stash["refill_key"], torch.uint32, (B, 2), "stash.refill_key")
+    depth = int(stash.get("depth", 1))
+    R = depth * B
+    nxt = _state_struct(stash["next"], R, m, N)
+    _check(stash["tag"], torch.uint32, (R, 2), "stash.tag")
+    _check(stash["ready_at"], torch.int32, (R,), "stash.ready_at")
+    _check(stash["refill_key"], torch.uint32, (R, 2), "stash.refill_key")
     _check(stash["hits"], torch.int32, (B,), "stash.hits")
     return nat.Stash(nxt, stash["tag"].data_ptr(), stash["ready_at"].data_ptr(),
-                     stash["refill_key"].data_ptr(), stash["hits"].data_ptr())
+                     stash["refill_key"].data_ptr(), stash["hits"].data_ptr(), depth)
 
 
 def connector_reset_prefetch(keys: torch.Tensor, m: int, N: int, stash: dict, tick: int,
@@ -326,7 +333,7 @@ def connector_step_prefetch(state: StateBufs, action: torch.Tensor, stash: dict,
 
 def stash_refill(stash: dict, m: int) -> None:
     """Launch the refill on torch's current stream."""
-    B, N = stash["next"]["start"].shape[0], stash["next"]["start"].shape[1]
+    B, N = stash["hits"].shape[0], stash["next"]["start"].shape[1]
     dev = stash["tag"].device
     h = _stash_struct(stash, B, m, N)
     nat.check(nat.lib().rbg_stash_refill(B, m, N, C.byref(h), _stream(dev)), "rbg_stash_refill")
@@ -345,12 +352,15 @@ class EpochStash:
     serial=False: the refill runs on a side stream and must be complete before the first launch
     of epoch e + 2 (one stream event per epoch); entries are usable from tick K * (e + 2) on."""
 
-    def __init__(self, B: int, m: int, N: int, device, every: int, serial: bool = True) -> None:
+    def __init__(self, B: int, m: int, N: int, device, every: int, serial: bool = True,
+                 depth: int = 1) -> None:
+        """depth=2: two slots per env, every entry requested a whole episode before it is needed
+        (include/rbg_prw.h::rbg_stash) -- for launches of many steps (connector_rollout)."""
         self.B, self.m, self.N, self.device = B, m, N, device
         self.K = max(1, int(every))
         self.serial = bool(serial)
         self.tick = 0
-        self.stash = alloc_stash(B, m, N, device)
+        self.stash = alloc_stash(B, m, N, device, depth)
         self.struct = _stash_struct(self.stash, B, m, N)
         self._lib = nat.lib()
         if not self.serial:
@@ -667,9 +677,12 @@ def connector_rollout(state: StateBufs, policy_keys: torch.Tensor, t0: int, n_st
                       time_limit: int = 50, timestep_reward: float = -0.03,
                       connected_reward: float = 0.1, auto_reset: bool = True,
                       state_out: Optional[StateBufs] = None, stats: Optional[dict] = None,
-                      timestep: Optional[TimestepBufs] = None, want_timestep: bool = False):
+                      timestep: Optional[TimestepBufs] = None, want_timestep: bool = False,
+                      epochs: Optional["EpochStash"] = None):
     """n_steps of random-policy stepping in one launch.  Returns (state_out, stats, timestep);
-    timestep is None unless a buffer dict is passed or want_timestep is set."""
+    timestep is None unless a buffer dict is passed or want_timestep is set.  `epochs` (an
+    EpochStash, best with depth=2 and every=1) serves the resets from the next-episode stash and
+    refills it behind the launch; same results."""
     B, m, _ = state["grid"].shape
     N = state["start"].shape[1]
     dev = state["grid"].device
@@ -689,6 +702,17 @@ def connector_rollout(state: StateBufs, policy_keys: torch.Tensor, t0: int, n_st
     p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
                       int(bool(auto_reset)))
     tp = _timestep_struct(ts, B, m, N) if ts is not None else None
+    if epochs is not None and auto_reset:
+        if (epochs.B, epochs.m, epochs.N) != (B, m, N):
+            raise ValueError("epochs was built for another batch / grid / agent count")
+        epochs.before_launch()
+        rc = nat.lib().rbg_connector_rollout_prefetch(
+            B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(), int(t0) & 0xFFFFFFFF,
+            int(n_steps), C.byref(p), C.byref(sp), C.byref(tp) if tp is not None else None,
+            C.byref(epochs.struct), epochs.tick, epochs.ready_delay(), _stream(dev))
+        epochs.after_launch()
+        nat.check(rc, "rbg_connector_rollout_prefetch")
+        return so, st, ts
     nat.check(nat.lib().rbg_connector_rollout(
         B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(), int(t0) & 0xFFFFFFFF,
         int(n_steps), C.byref(p), C.byref(sp), C.byref(tp) if tp is not None else None,

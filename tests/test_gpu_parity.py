@@ -826,3 +826,42 @@ def test_long_auto_reset_rollouts_match_oracle(rbg, oracle, m, N, B, steps, tl):
         assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
     for sess in env.unwrapped._sessions.values():
         sess.drain()
+
+
+@pytest.mark.parametrize("m,N,B,n_steps,tl", [(16, 10, 1024, 50, 50), (10, 5, 777, 40, 9),
+                                              (16, 10, 512, 120, 25)])
+def test_rollout_with_two_slot_stash_equals_plain_rollout(rbg, torch_mod, m, N, B, n_steps, tl):
+    """rbg_connector_rollout_prefetch with a depth-2 stash refilled after every launch: same
+    states and counters as the plain fused rollout, and once warm every reset is a stash hit --
+    including the second and third reset of an env within one launch (short time limits)."""
+    from routing_board_generation_amd import ops
+
+    keys, pkeys = _keys(rbg, 301, B), _keys(rbg, 302, B)
+    launches = 6
+    ref, _ = ops.connector_reset(keys, m, N)
+    ref_stats = []
+    for i in range(launches):
+        ref, st, _ = ops.connector_rollout(ref, pkeys, i * n_steps, n_steps, time_limit=tl)
+        ref_stats.append({k: v.clone() for k, v in st.items()})
+    ep = ops.EpochStash(B, m, N, keys.device, every=1, serial=True, depth=2)
+    ep.before_launch()
+    cur, _ = ops.connector_reset_prefetch(keys, m, N, ep.stash, ep.tick, ep.ready_delay())
+    ep.after_launch()
+    episodes = 0
+    for i in range(launches):
+        before = int(ep.stash["hits"].sum().item())
+        cur, st, _ = ops.connector_rollout(cur, pkeys, i * n_steps, n_steps, time_limit=tl,
+                                           epochs=ep)
+        for k in ops.ROLLOUT_STATS:
+            assert torch_mod.equal(st[k], ref_stats[i][k]), (i, k)
+        n_ep = int(st["episodes"].sum().item())
+        hits = int(ep.stash["hits"].sum().item()) - before
+        if i >= 1 and tl * 2 >= n_steps:  # at most two resets per env and launch: all served
+            assert hits == n_ep, (i, hits, n_ep)
+        episodes += n_ep
+    for k in ("grid", "step_count", "start", "target", "position"):
+        assert torch_mod.equal(cur[k], ref[k]), k
+    assert torch_mod.equal(cur["key"].view(torch_mod.int32), ref["key"].view(torch_mod.int32))
+    # two slots serve at most two resets per env and launch; the rest walk inline
+    total_hits = int(ep.stash["hits"].sum().item())
+    assert total_hits > (0.6 if tl * 2 >= n_steps else 0.3) * episodes, (total_hits, episodes)
