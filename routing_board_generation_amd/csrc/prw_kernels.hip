@@ -219,11 +219,12 @@ __global__ __launch_bounds__(kBlock) void uniform_generate_kernel(UniformArgs a)
 // Pre-generated next-episode states (include/rbg_prw.h::rbg_stash).  `next` of env b is the
 // State the auto-reset of an episode with State.key == tag[b] must produce.
 struct StashPtrs {
-  StatePtrs next;
-  uint32_t *tag;         // [B][2]
-  int32_t *ready_at;     // [B] first launch tick that may consume the entry
-  uint32_t *refill_key;  // [B][2] State.key of the running episode = the entry wanted next
+  StatePtrs next;        // depth * B rows; slot s of env b = row s * B + b
+  uint32_t *tag;         // [depth*B][2]
+  int32_t *ready_at;     // [depth*B] first launch tick that may consume the row
+  uint32_t *refill_key;  // [depth*B][2] the State.key whose successor the row should hold next
   int32_t *hits;         // [B] nullable diagnostics: resets served from the stash
+  int depth;             // 1 or 2
 };
 
 struct EnvArgs {
@@ -240,12 +241,54 @@ struct EnvArgs {
   int tick, ready_delay;
 };
 
-// after a (re)start: ask the next refill for the entry of the new episode's key
-__device__ __forceinline__ void request_refill(const StashPtrs &st, int b, int lane, Key2 key,
-                                               int ready_at) {
-  if (st.refill_key && lane == 0) {
-    *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)b]) = make_uint2(key.a, key.b);
-    st.ready_at[b] = ready_at;
+// Row of the stash that holds the successor of the episode with State.key `key`, or -1.
+__device__ __forceinline__ int stash_lookup(const StashPtrs &st, int B, int b, Key2 key,
+                                            int tick) {
+  int row = -1;
+  if (st.tag) {
+    for (int s = 0; s < st.depth; ++s) {
+      const int r = s * B + b;
+      const uint2 tag = *reinterpret_cast<const uint2 *>(&st.tag[2 * (size_t)r]);
+      if (tick >= st.ready_at[r] && tag.x == key.a && tag.y == key.b) row = r;
+    }
+  }
+  return row;
+}
+
+// After a (re)start with State.key `key`: ask the next refill for what comes after it
+// (include/rbg_prw.h::rbg_stash).  depth 1: the env's one row is requested for `key`.  depth 2:
+// one row is reserved for `key` unless one already is, and the other -- just consumed, or never
+// used -- is requested for the key of the episode after the next, split(split(key)[0])[0]
+// (VmapAutoResetWrapper's split, then the generator's).  Called by the whole sub-wave.
+template <int LPB>
+__device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const StashPtrs &st, int B,
+                                               int b, Key2 key, int ready_at) {
+  if (!st.refill_key) return;
+  if (st.depth == 1) {
+    if (sw.l == 0) {
+      *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)b]) = make_uint2(key.a, key.b);
+      st.ready_at[b] = ready_at;
+    }
+    return;
+  }
+  Key2 rk, after, unused;
+  split2_lanes(sw, key, rk, unused);
+  split2_lanes(sw, rk, after, unused);
+  if (sw.l == 0) {
+    const int r0 = b, r1 = B + b;
+    const uint2 k0 = *reinterpret_cast<const uint2 *>(&st.refill_key[2 * (size_t)r0]);
+    const uint2 k1 = *reinterpret_cast<const uint2 *>(&st.refill_key[2 * (size_t)r1]);
+    int other = r1;
+    if (k0.x == key.a && k0.y == key.b) {
+      other = r1;
+    } else if (k1.x == key.a && k1.y == key.b) {
+      other = r0;
+    } else {
+      *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)r0]) = make_uint2(key.a, key.b);
+      st.ready_at[r0] = ready_at;
+    }
+    *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)other]) = make_uint2(after.a, after.b);
+    st.ready_at[other] = ready_at;
   }
 }
 
@@ -267,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     kin.b = a.keys[2 * (size_t)b + 1];
     const Key2 key = regenerate(sw, board, W, g, N, kin, ag);
     store_state(sw, board, g, N, b, ag, 0, key, a.out);
-    request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
+    request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
     write_observation(sw, board, g, N, b, ag, 0, a.ts,
                       lane < N ? action_mask_bits(board, g, ag, lane) : 1u);
     write_extras(sw, board, g, N, b, ag, a.ts);
@@ -301,13 +344,9 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
     // and is only copied here; the entry is valid iff it was generated for exactly this
     // episode's key and the refill that wrote it is known to have completed (ready_at: ordered
     // by the host through the stream, never through in-kernel flags).
-    bool hit = false;
-    if (a.stash.tag) {
-      const uint2 tag = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
-      hit = a.tick >= a.stash.ready_at[b] && tag.x == key.a && tag.y == key.b;
-    }
-    if (hit) {
-      load_state(sw, board, g, N, b, a.stash.next, ag, step_count, key);
+    const int row = stash_lookup(a.stash, a.B, b, key, a.tick);
+    if (row >= 0) {
+      load_state(sw, board, g, N, row, a.stash.next, ag, step_count, key);
       if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
     } else {
       Key2 rk, unused;
@@ -315,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
       key = regenerate(sw, board, W, g, N, rk, ag);
     }
     step_count = 0;
-    request_refill(a.stash, b, lane, key, a.tick + a.ready_delay);
+    request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
     bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
   }
   store_state(sw, board, g, N, b, ag, step_count, key, a.out);
@@ -376,7 +415,7 @@ struct RolloutArgs {
   rbg_env_params p;
   RolloutStatsPtrs stats;
   TimestepPtrs ts;  // timestep of the LAST step of the rollout (all members nullable)
-  StashPtrs stash;  // optional next-episode stash: serves the FIRST reset of an env per launch
+  StashPtrs stash;  // optional next-episode stash
   int tick, ready_delay;
 };
 
@@ -409,11 +448,20 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_
   pk.b = a.policy_keys[2 * (size_t)b + 1];
 
   int episodes = 0, conn_made = 0, pen_steps = 0, fin_conn = 0, fin_plen = 0;
-  bool used_stash = false;
   uint32_t bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
+  // the policy's random word does not depend on the env: the one of step s + 1 is computed
+  // inside step s (rbg_env.h::PolicyFill)
+  PolicyFill pf;
+  pf.k = pk;
+  pf.i = (uint32_t)l;
+  pf.t = a.t0;
+  pf.first();
+  pf.second();
   for (int s = 0; s < a.n_steps; ++s) {
-    const int act = random_policy_action(pk, a.t0 + (uint32_t)s, (uint32_t)l, bits);
-    const StepResult res = env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit);
+    const int act = policy_pick(pf.y0, bits);
+    pf.t = a.t0 + (uint32_t)s + 1u;
+    const StepResult res =
+        env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit, pf);
     bits = res.bits;
     conn_made += __popcll(sw.ballot(!res.was_connected && res.connected));
     pen_steps += __popcll(sw.ballot(is_agent && !res.was_connected));
@@ -427,14 +475,10 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_
       fin_conn += __popcll(sw.ballot(res.connected));
       if (a.stats.final_path_length) fin_plen += count_path_cells(sw, board, g);
       if (a.p.auto_reset) {
-        bool hit = false;
-        if (a.stash.tag && !used_stash) {
-          const uint2 tag = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
-          hit = a.tick >= a.stash.ready_at[b] && tag.x == key.a && tag.y == key.b;
-        }
-        if (hit) {
-          load_state(sw, board, g, N, b, a.stash.next, ag, step_count, key);
-          used_stash = true;  // the entry is consumed; later resets of this launch walk inline
+        // (rows do not change during a launch: a second reset finds its own row or none)
+        const int row = stash_lookup(a.stash, a.B, b, key, a.tick);
+        if (row >= 0) {
+          load_state(sw, board, g, N, row, a.stash.next, ag, step_count, key);
           if (a.stash.hits && l == 0) a.stash.hits[b] += 1;
         } else {
           Key2 rk, unused;
@@ -442,7 +486,7 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_
           key = regenerate(sw, board, W, g, N, rk, ag);
         }
         step_count = 0;
-        request_refill(a.stash, b, l, key, a.tick + a.ready_delay);
+        request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
         bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
       }
     }
@@ -747,6 +791,11 @@ static int fill_stash(const rbg_stash *stash, StashPtrs *out, const char *who) {
   out->ready_at = stash->ready_at;
   out->refill_key = stash->refill_key;
   out->hits = stash->hits;
+  out->depth = stash->depth;
+  if (stash->depth != 1 && stash->depth != 2) {
+    snprintf(g_err, sizeof(g_err), "%s: stash depth must be 1 or 2", who);
+    return RBG_E_PARAM;
+  }
   return 0;
 }
 
@@ -801,9 +850,10 @@ int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream) 
   if (!stash) return fail(RBG_E_NULL, "rbg_stash_refill: NULL stash");
   if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_stash_refill")) return rc;
-  a.B = B; a.N = N;
+  a.B = B * stash->depth;  // the kernel works on rows
+  a.N = N;
   const int envs_per_block = kWavesPerBlock * (kWaveSize / lpb);
-  const dim3 grid((B + envs_per_block - 1) / envs_per_block), block(kBlock);
+  const dim3 grid((a.B + envs_per_block - 1) / envs_per_block), block(kBlock);
   const size_t lds = lds_bytes(a.g, lpb);
   hipStream_t st = (hipStream_t)stream;
   if (lpb == 16) {

@@ -220,10 +220,20 @@ struct StepResult {
 // _step_agent: move iff the action is not NOOP, the destination is in bounds and empty or the
 // agent's own target, and the agent is not connected yet.  Only an EMPTY cell can be contested
 // (a target cell admits its owner alone): max-join through one ds_max_u32, losers stay.
-template <int LPB>
+// `fill` is independent register-only work of the caller (the rollout's Threefry for the NEXT
+// step) that is issued into the two LDS round trips of the move: fill.first() after the read of
+// the destination cell, fill.second() after the ds_max + read-back.  A lone env step is a chain of
+// dependent instructions and LDS latencies; with two waves per SIMD little else hides them.
+struct NoFill {
+  __device__ __forceinline__ void first() {}
+  __device__ __forceinline__ void second() {}
+};
+
+template <int LPB, class Fill>
 __device__ __forceinline__ StepResult env_step_core(const SubWave<LPB> &sw, uint32_t *board,
                                                     const Geo &g, int N, AgentRegs &ag,
-                                                    int &step_count, int act, int time_limit) {
+                                                    int &step_count, int act, int time_limit,
+                                                    Fill &fill) {
   const int lane = sw.l;
   const bool is_agent = lane < N;
   const uint32_t head = 3u * (uint32_t)lane + 2u;
@@ -235,12 +245,19 @@ __device__ __forceinline__ StepResult env_step_core(const SubWave<LPB> &sw, uint
   const int P = pad_index(g, ag.r, ag.c);
   const int Q = P + dr * g.S + dc;
   const uint32_t vq = board[Q];
+  __builtin_amdgcn_sched_barrier(0);
+  fill.first();
+  __builtin_amdgcn_sched_barrier(0);
   const bool to_empty = vq == 0u;
   const bool to_target = vq == head + 1u;
   const bool mover = is_agent && act != 0 && !res.was_connected && (to_empty || to_target);
   if (mover && to_empty) atomicMax(&board[Q], head);
   wave_lds_fence();
-  if (mover && (to_target || board[Q] == head)) {
+  const uint32_t back = board[Q];  // (Q is a valid padded index for every lane)
+  __builtin_amdgcn_sched_barrier(0);
+  fill.second();
+  __builtin_amdgcn_sched_barrier(0);
+  if (mover && (to_target || back == head)) {
     board[Q] = head;  // overwrites the own target on arrival (move_agent)
     board[P] = head - 1u;
     ag.r += dr;
@@ -254,6 +271,14 @@ __device__ __forceinline__ StepResult env_step_core(const SubWave<LPB> &sw, uint
   const bool all_done = sw.ballot(is_agent && !res.done) == 0ull;
   res.last = all_done || step_count >= time_limit;
   return res;
+}
+
+template <int LPB>
+__device__ __forceinline__ StepResult env_step_core(const SubWave<LPB> &sw, uint32_t *board,
+                                                    const Geo &g, int N, AgentRegs &ag,
+                                                    int &step_count, int act, int time_limit) {
+  NoFill none;
+  return env_step_core(sw, board, g, N, ag, step_count, act, time_limit, none);
 }
 
 // DenseRewardFn
@@ -354,10 +379,7 @@ __device__ __forceinline__ void write_step_outcome(const SubWave<LPB> &sw, const
 // masked-uniform random policy (defined by this project; include/rbg_prw.h): agent i of an env
 // with policy key k picks, at global step t, legal action number
 //   floor(threefry2x32(k, (t, i)).y0 * #legal / 2^32)   (legal actions in ascending order).
-__device__ __forceinline__ int random_policy_action(Key2 k, uint32_t t, uint32_t i,
-                                                    uint32_t mask_bits) {
-  uint32_t y0, y1;
-  threefry(k.a, k.b, t, i, y0, y1);
+__device__ __forceinline__ int policy_pick(uint32_t y0, uint32_t mask_bits) {
   const int cnt = __popc(mask_bits & 31u);
   const int pick = (int)__umulhi(y0, (uint32_t)cnt);
   int chosen = 0, seen = 0;
@@ -370,5 +392,28 @@ __device__ __forceinline__ int random_policy_action(Key2 k, uint32_t t, uint32_t
   }
   return chosen;
 }
+
+__device__ __forceinline__ int random_policy_action(Key2 k, uint32_t t, uint32_t i,
+                                                    uint32_t mask_bits) {
+  uint32_t y0, y1;
+  threefry(k.a, k.b, t, i, y0, y1);
+  return policy_pick(y0, mask_bits);
+}
+
+// The policy's random word of one (step, agent), computed in the shadow of the previous step.
+struct PolicyFill {
+  Key2 k;
+  uint32_t t, i;  // counter of the word being produced
+  TfState st;
+  uint32_t y0;
+  __device__ __forceinline__ void first() {
+    st = threefry_first_half(k.a, k.b, t, i);
+    asm volatile("" : "+v"(st.x0), "+v"(st.x1));  // keep the rounds where they are issued
+  }
+  __device__ __forceinline__ void second() {
+    uint32_t y1;
+    threefry_second_half(st, y0, y1);
+  }
+};
 
 }  // namespace rbg
