@@ -540,11 +540,12 @@ def main() -> None:
                        "sharding": f"batch-sharded x{world}, no data-path collective",
                        "mean_walk_iters": metrics["iters"] / (B * world),
                        "max_walk_iters": metrics["max_iters"]},
-            "roofline": roofline, "cpu_baseline": cpu, "pipelined": pipelined, "env_step": env_step,
-            "rollout": rollout,
+            "roofline": roofline, "cpu_baseline": cpu, "env_step": env_step, "rollout": rollout,
         }
+        if pipelined is not None:
+            line["pipelined"] = pipelined
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
