@@ -17,8 +17,9 @@ _LIB_PATH = os.path.join(_HERE, "libprw_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "prw_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("prw_oracle.c", "seed_extension.c", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libprw_oracle.so"])
     return _LIB_PATH
 
@@ -29,8 +30,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_uniform.restype = C.c_float
     return _lib
@@ -379,3 +379,30 @@ def seq_rw_generator_batch(keys, m, N, threads=1):
     if rc != 0:
         raise ValueError("oracle_seq_rw_generator_batch: bad arguments")
     return st, solved, attempts
+
+
+def randint_vec(key, n, lo, hi):
+    """[3P] jax.random.randint(key, (n,), lo, hi), the C restatement used by SeedExtension."""
+    key = _u32(key)
+    out = np.zeros(n, np.int32)
+    lib().oracle_randint(_p(key), n, int(lo), int(hi), _p(out))
+    return out
+
+
+def seed_extension_batch(keys, m, N, split_first=True, randomness=0.0, two_sided=True,
+                         extension_iterations=1, extension_steps=1e23, threads=1):
+    """vmap(SeedExtensionGenerator(m, N).__call__) (split_first) or
+    vmap(SeedExtensionBoard(m, m, N).generate_starts_ends) (not split_first) over keys [B,2]
+    -> (state dict, solved [B,m,m], sweeps [B])."""
+    keys = _u32(keys).reshape(-1, 2)
+    B = keys.shape[0]
+    st = alloc_state(B, m, N)
+    solved = np.zeros((B, m, m), np.int32)
+    sweeps = np.zeros((B,), np.int32)
+    rc = lib().oracle_seed_extension_batch(
+        _p(keys), B, m, N, int(bool(split_first)), C.c_float(randomness), int(bool(two_sided)),
+        int(extension_iterations), C.c_double(extension_steps),
+        *[_p(st[k]) for k in _STATE_ORDER], _p(solved), _p(sweeps), threads)
+    if rc != 0:
+        raise ValueError("oracle_seed_extension_batch: bad arguments (rc=%d)" % rc)
+    return st, solved, sweeps

@@ -263,3 +263,95 @@ def test_sequential_random_walk_retries_and_failure(oracle):
     assert (st["grid"][failed][:, 0, 0] == 21).all()
     for b in np.flatnonzero(~failed)[:20]:
         check_solved_board(solved[b], st["start"][b], st["target"][b])
+
+
+# --------------------------------------------------------------------------- SeedExtension (G8)
+def test_seed_extension_batch100_golden(oracle, goldens):  # profiling nb cell 23
+    """vmap(SeedExtensionGenerator(10, 5).__call__) over split(PRNGKey(0), 100): every printed
+    value of the reference's executed notebook is reproduced -- all 1000 start and 1000 target
+    coordinates, the 100 State keys and the 6x6x6 corner windows of the training grids.  This pins
+    _randint, the seeding, extend_wires_jax (flips, key threading, choice loop, stopping rule)
+    for the defaults randomness=0, two_sided=True, extension_iterations=1."""
+    b = goldens["notebook"]["batch100_10x10_5_split_PRNGKey0"]["seed_extension"]
+    keys = oracle.split(oracle.prng_key(0), 100)
+    st, solved, sweeps = oracle.seed_extension_batch(keys, 10, 5)
+    assert (st["key"] == np.asarray(b["key"], np.uint32)).all()
+    assert (st["start"] == np.asarray(b["start"], np.int32)).all()
+    assert (st["target"] == np.asarray(b["target"], np.int32)).all()
+    assert (st["position"] == np.asarray(b["position"], np.int32)).all()
+    win = st["grid"][np.ix_(WINDOW_BOARDS, WINDOW, WINDOW)]
+    assert (win == np.asarray(b["grid_window"], np.int32)).all()
+    assert (st["step_count"] == 0).all()
+    assert sweeps.min() >= 1
+    _check_seed_extension_boards(solved, st["start"], st["target"])
+
+
+def test_seed_extension_single_board_golden_is_stale(oracle, goldens):  # profiling nb cell 10
+    """The single-board cell of the notebook was executed with an older reference (it imports the
+    class as RandomSeedGenerator).  What today's code still shares with it: State.key and the two
+    endpoints that never move (wire 0 head (6,5), wire 3 target (5,5)) -- they equal the SEEDED
+    board of today's return_seeded_board.  The rest of that cell is 'parity unpinned, G8 stale'."""
+    g = goldens["notebook"]["single_10x10_5_PRNGKey0"]["seed_extension"]
+    st, _, _ = oracle.seed_extension_batch(oracle.prng_key(0)[None], 10, 5, extension_iterations=0)
+    assert st["key"][0].tolist() == g["key"]
+    assert st["start"][0, 0].tolist() == g["start"][0] == [6, 5]
+    assert st["target"][0, 3].tolist() == g["target"][3] == [5, 5]
+
+
+def _check_seed_extension_boards(solved, start, target):
+    """Every wire is a simple chain from its POSITION cell to its TARGET cell (what
+    NPI/utils/post_processor_utils_numpy.py:90-121 verifies), endpoints where State says."""
+    from helpers import same_wire_neighbour_count
+    B, m, _ = solved.shape
+    N = start.shape[1]
+    cnt = same_wire_neighbour_count(solved)
+    kind = np.where(solved > 0, (solved - 1) % 3, -1)
+    assert (solved >= 0).all() and (solved <= 3 * N).all()
+    assert (cnt[kind == 0] == 2).all()
+    assert (cnt[kind > 0] == 1).all()
+    bb = np.arange(B)[:, None]
+    i = np.arange(N)[None, :]
+    assert (solved[bb, start[..., 0], start[..., 1]] == 2 + 3 * i).all()
+    assert (solved[bb, target[..., 0], target[..., 1]] == 3 + 3 * i).all()
+    for v in (2, 3):
+        assert ((solved[:, :, :, None] == v + 3 * np.arange(N)).sum((1, 2)) == 1).all()
+
+
+@pytest.mark.parametrize("m,N,kw", [
+    (10, 5, dict(randomness=1.0, two_sided=False)),      # BoardDatasetGeneratorJAX defaults
+    (10, 5, dict(randomness=0.85, extension_iterations=3)),
+    (16, 10, dict()),
+    (8, 16, dict(randomness=0.3)),                       # every candidate cell seeded
+    (5, 2, dict(extension_iterations=2)), (7, 4, dict()), (2, 1, dict()), (3, 1, dict()),
+    (16, 10, dict(extension_steps=2)),
+])
+def test_seed_extension_invariants(oracle, m, N, kw):
+    """Unpinned parameter space (randomness > 0, one-sided, several extension iterations, odd
+    sizes): structural invariants of the restatement + endpoints untouched by optimise_wire."""
+    keys = oracle.split(oracle.prng_key(11), 64)
+    st, solved, sweeps = oracle.seed_extension_batch(keys, m, N, **kw)
+    _check_seed_extension_boards(solved, st["start"], st["target"])
+    if kw.get("extension_steps"):
+        assert (sweeps <= kw["extension_steps"] * kw.get("extension_iterations", 1)).all()
+    if not kw.get("two_sided", True):
+        # heads never move: they sit where the seeding put them
+        seeded, _, _ = oracle.seed_extension_batch(keys, m, N, extension_iterations=0, **{
+            k: v for k, v in kw.items() if k != "extension_iterations"})
+        assert (seeded["start"] == st["start"]).all()
+    # board-level entry (generate_starts_ends) = generator entry on split(key)[0]
+    k0 = np.stack([oracle.split(k)[0] for k in keys])
+    st2, solved2, _ = oracle.seed_extension_batch(k0, m, N, split_first=False, **kw)
+    assert (solved2 == solved).all() and (st2["start"] == st["start"]).all()
+
+
+def test_seed_extension_rejects_too_many_agents(oracle):
+    with pytest.raises(ValueError):
+        oracle.seed_extension_batch(oracle.prng_key(0)[None], 10, 26)  # 25 candidate cells
+
+
+def test_randint_matches_scalar_form(oracle):
+    # the vector form with n = 1 is the scalar jax.random.randint used by the dataset sampler
+    for s in range(20):
+        k = oracle.split(oracle.prng_key(s))[1]
+        for span in (2, 4, 7, 100, 65537):
+            assert int(oracle.randint_vec(k, 1, 0, span)[0]) == oracle.randint(k, 0, span)
