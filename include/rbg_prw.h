@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 3
+#define RBG_ABI_VERSION 4
 
 #define RBG_E_NULL (-1)   /* a required pointer is NULL */
 #define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
@@ -122,6 +122,35 @@ int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_fir
                         int32_t *solved_grid, int32_t *train_grid, int32_t *start,
                         int32_t *target, int32_t *position, int32_t *step_count,
                         uint32_t *key_out, int32_t *attempts, void *stream);
+
+/* vmap(SeedExtensionBoard(m, m, N).generate_starts_ends)(keys, randomness, two_sided,
+ *      extension_iterations, extension_steps)                               [split_first == 0]
+ *   JAXI/seed_extension.py:257-304 (and :149-227 return_solved_board for solved_grid); the call
+ *   shape of routing_board_generation/rl_training/offline_generation/dataset_generator_jax.py:79-98
+ * vmap(SeedExtensionGenerator(m, N).__call__)(keys)                          [split_first != 0]
+ *   routing_board_generation/rl_training/online_generators/random_seed_generator.py:28-57
+ *   (adds `key, _ = split(key)`; key_out = State.key; the reference's defaults there are
+ *    randomness = 0, two_sided = 1, extension_iterations = 1, no step limit)
+ * The algorithm: seed N adjacent (target, head) pairs (seed_extension.py:93-147), extend both
+ * ends cell by cell over randomly flipped row-major sweeps until an un-flipped sweep changes
+ * nothing (JAXI/../utils/post_processor_utils_jax.py:24-195), then re-route every wire along a
+ * BFS-shortest path (JAXI/../utils/grid_utils.py:491-612), extension_iterations times.
+ *   randomness            float32: P(ignore the straight-ahead direction) per extension
+ *   two_sided             != 0: heads and targets extend; 0: targets only
+ *   max_extension_steps   sweeps allowed per extension (the reference's `extension_steps`, whose
+ *                         default 1e23 means no limit: pass INT32_MAX)
+ * Same outputs as rbg_prw_generate (start = the wires' POSITION cells, target = their TARGET
+ * cells); solved_grid, when given, also triggers the final re-routing pass, which no other
+ * output can see.  sweeps (nullable) int32 [B] = extension sweeps the board took.
+ * extension_iterations == -1 (with split_first == 0): return_seeded_board(keys)
+ * (seed_extension.py:93-147) -- the keys are the seed keys themselves and nothing is extended.
+ * N <= (m / 2)^2 (the candidate seed cells). */
+int rbg_seed_extension_generate(const uint32_t *keys, int B, int m, int N, int split_first,
+                                float randomness, int two_sided, int extension_iterations,
+                                int max_extension_steps, int32_t *solved_grid, int32_t *train_grid,
+                                int32_t *start, int32_t *target, int32_t *position,
+                                int32_t *step_count, uint32_t *key_out, int32_t *sweeps,
+                                void *stream);
 
 /* vmap(UniformRandomGenerator(m, N).__call__)(keys)
  *   routing_board_generation/rl_training/online_generators/uniform_generator.py:70-109
@@ -245,9 +274,11 @@ int rbg_connector_rollout(int B, int m, int N, const rbg_state *state_in,
                           const rbg_rollout_stats *stats, const rbg_timestep *last_timestep,
                           void *stream);
 
-/* rbg_connector_rollout with a stash: the FIRST reset of an env inside the launch may take its
- * State from the stash, later ones walk inline (with n_steps = 1 and last_timestep set this is a
- * fused "random policy + step" launch, one kernel per env step). */
+/* rbg_connector_rollout with a stash: every reset of an env inside the launch takes its State
+ * from the stash when a matching row is ready -- with depth 2 that includes the second reset of
+ * an env that finishes two episodes within the launch; a reset without a ready row walks inline
+ * (with n_steps = 1 and last_timestep set this is a fused "random policy + step" launch, one
+ * kernel per env step). */
 int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_in,
                                    const rbg_state *state_out, const uint32_t *policy_keys,
                                    uint32_t t0, int n_steps, const rbg_env_params *params,

@@ -9,9 +9,11 @@ from .board_generation.parallel_random_walk import ParallelRandomWalkBoard  # no
 from .connector import (Connector, DenseRewardFn, MultiToSingleWrapper,  # noqa: F401
                         VmapAutoResetWrapper)
 from .interface.board_generator_interface import BoardGenerator, BoardName  # noqa: F401
-from .offline_generation import BoardDatasetGenerator  # noqa: F401
+from .offline_generation import BoardDatasetGenerator, BoardDatasetGeneratorJAX  # noqa: F401
+from .board_generation.seed_extension import SeedExtensionBoard  # noqa: F401
 from .board_generation.sequential_random_walk import SequentialRandomWalkBoard  # noqa: F401
 from .online_generators import (Generator, ParallelRandomWalkGenerator,  # noqa: F401
+                                RandomSeedGenerator, SeedExtensionGenerator,
                                 SequentialRandomWalkGenerator, UniformRandomGenerator)
 from .random import PRNGKey, split  # noqa: F401
 from .types import Agent, Observation, State, StepType, TimeStep  # noqa: F401

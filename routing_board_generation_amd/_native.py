@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
 HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
                "-std=c++17"]
 
@@ -65,6 +65,10 @@ SIGNATURES = {
     "rbg_seq_rw_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rbg_seed_extension_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rbg_uniform_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),

@@ -5,6 +5,7 @@
 //   rbg_walk.h     ParallelRandomWalk (one board per sub-wave of 16/32/64 lanes)
 //   rbg_env.h      Connector reset / step / observation pieces (one env per sub-wave)
 //   rbg_seqwalk.h  SequentialRandomWalk (one board per wavefront)
+//   rbg_seedext.h  SeedExtension (one board per sub-wave; chain phase + event phase + exact BFS)
 // Common design:
 //   * a board lives in LDS as a "padded" image (2 wall rows above/below, 4 wall columns shared
 //     between consecutive rows) so that the 4-neighbour and neighbour-of-neighbour stencils need
@@ -28,6 +29,7 @@
 #include "rbg_walk.h"
 #include "rbg_env.h"
 #include "rbg_seqwalk.h"
+#include "rbg_seedext.h"
 
 namespace {
 
@@ -160,6 +162,58 @@ __global__ __launch_bounds__(kBlock) void seq_rw_generate_kernel(GenArgs a) {
     if (a.key_out) *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(key.a, key.b);
     if (a.step_count) a.step_count[b] = 0;
     if (a.iters) a.iters[b] = attempts;
+  }
+}
+
+struct SeArgs {
+  GenArgs gen;  // iters = sweeps per board
+  SeParams p;
+};
+
+// SeedExtensionBoard.generate_starts_ends / return_solved_board and
+// SeedExtensionGenerator.__call__ (rbg_seedext.h); blockDim.x / 64 waves per workgroup
+template <int LPB>
+__global__ __launch_bounds__(kBlock) void seed_extension_kernel(SeArgs args) {
+  constexpr int kSubs = SubWave<LPB>::kSubs;
+  const GenArgs &a = args.gen;
+  const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpb = (int)(blockDim.x >> 6);
+  const int first = (blockIdx.x * wpb + wib) * kSubs;
+  if (first >= a.B) return;  // wave-uniform; waves never synchronise with each other
+  const Geo g = a.g;
+  // boards past the end of the batch redo the wave's first board and store nothing
+  const bool valid = first + sw.h < a.B;
+  const int b = valid ? first + sw.h : first;
+  const int per_board = slab_words<LPB>(g) + se_extra_words(g.words, g.n);
+  uint32_t *board = g_lds + (wib * kSubs + sw.h) * per_board;
+  uint32_t *scr = board + board_words(g);
+  uint32_t *xtra = board + slab_words<LPB>(g);
+
+  Key2 key;
+  key.a = a.keys[2 * (size_t)b];
+  key.b = a.keys[2 * (size_t)b + 1];
+  if (a.split_first) {  // key, pos_key = split(key)  (random_seed_generator.py:34)
+    Key2 unused;
+    split2_lanes(sw, key, key, unused);
+  }
+  int pr, pc, tr, tc;
+  const int sweeps = seed_extension_generate(sw, board, scr, xtra, g, args.p, key, pr, pc, tr, tc);
+  if (!valid) return;
+
+  const size_t gofs = (size_t)b * g.n;
+  if (a.solved_grid) store_grid<LPB, false>(board, g, sw.l, a.solved_grid + gofs);
+  if (a.train_grid) store_grid<LPB, true>(board, g, sw.l, a.train_grid + gofs);
+  if (sw.l < a.N) {
+    const size_t o = ((size_t)b * a.N + sw.l) * 2;
+    *reinterpret_cast<int2 *>(&a.start[o]) = make_int2(pr, pc);
+    *reinterpret_cast<int2 *>(&a.target[o]) = make_int2(tr, tc);
+    if (a.position) *reinterpret_cast<int2 *>(&a.position[o]) = make_int2(pr, pc);
+  }
+  if (sw.l == 0) {
+    if (a.key_out) *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(key.a, key.b);
+    if (a.step_count) a.step_count[b] = 0;
+    if (a.iters) a.iters[b] = sweeps;
   }
 }
 
@@ -739,6 +793,66 @@ int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_fir
   hipLaunchKernelGGL(seq_rw_generate_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
                      dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
   return check_hip(hipGetLastError(), "rbg_seq_rw_generate");
+}
+
+int rbg_seed_extension_generate(const uint32_t *keys, int B, int m, int N, int split_first,
+                                float randomness, int two_sided, int extension_iterations,
+                                int max_extension_steps, int32_t *solved_grid, int32_t *train_grid,
+                                int32_t *start, int32_t *target, int32_t *position,
+                                int32_t *step_count, uint32_t *key_out, int32_t *sweeps,
+                                void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_seed_extension_generate: B < 0");
+  SeArgs args;
+  GenArgs &a = args.gen;
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (N > (m / 2) * (m / 2))
+    return fail(RBG_E_SHAPE, "rbg_seed_extension_generate: N exceeds the (m/2)^2 seed cells");
+  if (extension_iterations < -1 || max_extension_steps < 0)
+    return fail(RBG_E_PARAM, "rbg_seed_extension_generate: bad iteration / step count");
+  if (extension_iterations == -1 && split_first)
+    return fail(RBG_E_PARAM, "rbg_seed_extension_generate: seed-only takes the seed keys");
+  if (B == 0) return 0;
+  if (!keys || !start || !target)
+    return fail(RBG_E_NULL, "rbg_seed_extension_generate: NULL pointer");
+  if (int rc = check_align(a.g, solved_grid, train_grid, nullptr)) return rc;
+  a.keys = keys; a.B = B; a.N = N; a.split_first = split_first != 0;
+  a.solved_grid = solved_grid; a.train_grid = train_grid; a.start = start; a.target = target;
+  a.position = position; a.step_count = step_count; a.key_out = key_out; a.iters = sweeps;
+  SeParams &p = args.p;
+  p.N = N;
+  p.iterations = extension_iterations < 0 ? 0 : extension_iterations;
+  p.seed_only = extension_iterations < 0;
+  p.max_steps = max_extension_steps;
+  p.two_sided = two_sided != 0;
+  p.randomness = randomness;
+  // use_random = randomness > uniform, uniform in [0, 1)
+  p.rnd_mode = !(randomness > 0.0f) ? 0 : (randomness >= 1.0f ? 1 : 2);
+  p.bfs_last = solved_grid != nullptr;  // only the solved board can see the last re-routing
+  p.half = m / 2;
+  // lanes per board: lane w owns wire w; fewer, fuller waves as long as the workgroup's LDS fits
+  int lpb = 16;
+  while (lpb < N) lpb *= 2;
+  int wpb = kWavesPerBlock;
+  size_t lds = 0;
+  for (;;) {
+    const size_t per_board =
+        (size_t)((a.g.words + 3) & ~3) + (size_t)(4 * lpb) + (size_t)se_extra_words(a.g.words, a.g.n);
+    lds = (size_t)wpb * (size_t)(kWaveSize / lpb) * per_board * sizeof(uint32_t);
+    if (lds <= 64u * 1024u) break;
+    if (lpb < kWaveSize) lpb *= 2; else if (wpb > 1) wpb /= 2; else break;
+  }
+  if (lds > 64u * 1024u) return fail(RBG_E_SHAPE, "rbg_seed_extension_generate: board too large");
+  const int boards_per_block = wpb * (kWaveSize / lpb);
+  const dim3 grid((B + boards_per_block - 1) / boards_per_block), block(kWaveSize * wpb);
+  hipStream_t st = (hipStream_t)stream;
+  if (lpb == 16) {
+    hipLaunchKernelGGL(seed_extension_kernel<16>, grid, block, lds, st, args);
+  } else if (lpb == 32) {
+    hipLaunchKernelGGL(seed_extension_kernel<32>, grid, block, lds, st, args);
+  } else {
+    hipLaunchKernelGGL(seed_extension_kernel<64>, grid, block, lds, st, args);
+  }
+  return check_hip(hipGetLastError(), "rbg_seed_extension_generate");
 }
 
 int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *train_grid,

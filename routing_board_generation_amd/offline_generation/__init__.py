@@ -1,1 +1,1 @@
-from .dataset_generator import BoardDatasetGenerator  # noqa: F401
+from .dataset_generator import BoardDatasetGenerator, BoardDatasetGeneratorJAX  # noqa: F401

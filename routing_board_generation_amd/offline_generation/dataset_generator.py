@@ -1,11 +1,16 @@
-"""BoardDatasetGenerator -- mirrors BoardDatasetGeneratorJAX of the reference
-(routing_board_generation/rl_training/offline_generation/dataset_generator_jax.py:20-141) for
-board_name "offline_parallel_rw" (and "offline_uniform"): a dataset of `number_of_boards` boards
-is generated once from split(PRNGKey(0), number_of_boards); `__call__(key)` samples one.
+"""BoardDatasetGeneratorJAX -- mirrors the reference class of the same name
+(routing_board_generation/rl_training/offline_generation/dataset_generator_jax.py:20-141): a
+dataset of `number_of_boards` boards is generated once from split(PRNGKey(0), number_of_boards)
+by SeedExtensionBoard.generate_starts_ends ("offline_seed_extension", the reference's default),
+ParallelRandomWalkBoard.generate_board ("offline_parallel_rw") or UniformRandomGenerator
+("offline_uniform"); `__call__(key)` samples one board of it.
 
 The reference builds the dataset with a Python loop of one jitted call per board (:76-105); here it
-is one batched launch.  Sampling follows [3P] jax.random.randint; no reference golden pins it
-("parity unpinned").
+is one batched launch.  Constructor signature and attribute layout follow the reference
+(`heads` / `targets` of shape (n_boards, 2, N), :57-63); the seed-extension keywords are accepted
+and ignored for the other board names, as the reference does (setup_train.py:121-130 passes them
+for "offline_parallel_rw" too).  Sampling follows [3P] jax.random.randint; no reference golden
+pins it ("parity unpinned").
 """
 import torch
 
@@ -15,28 +20,68 @@ from ..random import PRNGKey, split
 from ..types import State
 
 
-class BoardDatasetGenerator(Generator):
-    def __init__(self, grid_size: int, num_agents: int, board_name: str = "offline_parallel_rw",
-                 number_of_boards: int = 10000, device=None) -> None:
+class BoardDatasetGeneratorJAX(Generator):
+    def __init__(self, grid_size: int, num_agents: int, randomness: float = 1,
+                 two_sided: bool = False, extension_iterations: int = 1,
+                 extension_steps=1e23, board_name: str = "offline_seed_extension",
+                 number_of_boards: int = 10000, generate_solved_boards: bool = False,
+                 device=None) -> None:
         super().__init__(grid_size, num_agents)
         self.board_name = board_name
-        keys = split(PRNGKey(0, device=device), number_of_boards)
-        if board_name == "offline_parallel_rw":
-            out = ops.prw_generate(keys, grid_size, num_agents, split_first=False,
-                                   want_solved=True, want_train=False)
-            self.heads, self.targets = out["start"], out["target"]
-            self.solved_boards = out["solved_grid"]
+        keys = split(PRNGKey(0, device=device), number_of_boards)  # :57-58, :76
+        if board_name == "offline_seed_extension":
+            self.randomness = randomness
+            self.two_sided = two_sided
+            self.extension_iterations = extension_iterations
+            self.extension_steps = extension_steps
+            out = ops.seed_extension_generate(
+                keys, grid_size, num_agents, split_first=False, randomness=randomness,
+                two_sided=two_sided, extension_iterations=extension_iterations,
+                extension_steps=extension_steps, want_solved=bool(generate_solved_boards),
+                want_train=False)
+            self._heads, self._targets = out["start"], out["target"]
+            self.solved_boards = out.get("solved_grid")
         elif board_name == "offline_uniform":
             st = ops.uniform_generate(keys, grid_size, num_agents)
-            self.heads, self.targets, self.solved_boards = st["start"], st["target"], None
+            self._heads, self._targets, self.solved_boards = st["start"], st["target"], None
+        elif board_name == "offline_parallel_rw":
+            out = ops.prw_generate(keys, grid_size, num_agents, split_first=False,
+                                   want_solved=True, want_train=False)
+            self._heads, self._targets = out["start"], out["target"]
+            self.solved_boards = out["solved_grid"]
         else:
-            raise NotImplementedError(f"board_name {board_name!r} is outside the hot path")
+            # the reference's else-branch would run ParallelRandomWalk for ANY other string; a
+            # typo silently changing the generator is not worth mirroring
+            raise ValueError(f"unknown board_name {board_name!r}")
+
+    @property
+    def heads(self) -> torch.Tensor:
+        """(n_boards, 2, N): row and column arrays per board, as the reference holds them."""
+        return self._heads.transpose(-1, -2)
+
+    @property
+    def targets(self) -> torch.Tensor:
+        return self._targets.transpose(-1, -2)
 
     def __len__(self) -> int:
-        return self.heads.shape[0]
+        return self._heads.shape[0]
 
     def __call__(self, key: torch.Tensor) -> State:
         batched = key.dim() == 2
         keys = (key if batched else key[None]).contiguous()
-        st, _ = ops.dataset_sample(keys, self.heads, self.targets, self.grid_size)
+        st, _ = ops.dataset_sample(keys, self._heads, self._targets, self.grid_size)
         return state_from_bufs(st, batched)
+
+    def print_board(self, which_board: int) -> torch.Tensor:
+        """:143-155 -- the training grid of board `which_board`."""
+        grid = torch.zeros((self.grid_size, self.grid_size), dtype=torch.int32,
+                           device=self._heads.device)
+        ids = torch.arange(self.num_agents, dtype=torch.int32, device=grid.device)
+        h, t = self._heads[which_board].long(), self._targets[which_board].long()
+        grid[h[:, 0], h[:, 1]] = 2 + 3 * ids
+        grid[t[:, 0], t[:, 1]] = 3 + 3 * ids
+        return grid
+
+
+# round-1 name of this class (its heads/targets were agent-major then)
+BoardDatasetGenerator = BoardDatasetGeneratorJAX

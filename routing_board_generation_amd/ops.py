@@ -196,6 +196,49 @@ def seq_rw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool,
     return o
 
 
+INT32_MAX = 2 ** 31 - 1
+
+
+def extension_steps_to_int(extension_steps) -> int:
+    """The reference compares an int32 sweep counter with `extension_steps` in float32
+    (post_processor_utils_jax.py:51-55; default 1e23 = no limit): the number of sweeps allowed is
+    the smallest integer s with not (float32(s) < float32(extension_steps))."""
+    x = float(extension_steps)
+    if x != x or x <= 0.0:
+        return 0
+    if x >= float(1 << 24):  # beyond float32's exact integers: nothing reaches it
+        return INT32_MAX
+    import math
+    return min(INT32_MAX, int(math.ceil(x)))
+
+
+def seed_extension_generate(keys: torch.Tensor, m: int, N: int, split_first: bool,
+                            randomness: float = 0.0, two_sided: bool = True,
+                            extension_iterations: int = 1, extension_steps=1e23,
+                            want_solved: bool = False, want_train: bool = True):
+    """SeedExtension: dict(solved_grid?, train_grid?, start, target, position, step_count,
+    key_out, sweeps)."""
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    o = {"start": torch.empty((B, N, 2), **i32), "target": torch.empty((B, N, 2), **i32),
+         "position": torch.empty((B, N, 2), **i32), "step_count": torch.empty((B,), **i32),
+         "key_out": torch.empty((B, 2), dtype=torch.uint32, device=dev),
+         "sweeps": torch.empty((B,), **i32)}
+    if want_solved:
+        o["solved_grid"] = torch.empty((B, m, m), **i32)
+    if want_train:
+        o["train_grid"] = torch.empty((B, m, m), **i32)
+    nat.check(nat.lib().rbg_seed_extension_generate(
+        keys.data_ptr(), B, m, N, int(split_first), float(randomness), int(bool(two_sided)),
+        int(extension_iterations), extension_steps_to_int(extension_steps),  # -1: seed only
+        _ptr(o.get("solved_grid")), _ptr(o.get("train_grid")), o["start"].data_ptr(),
+        o["target"].data_ptr(), o["position"].data_ptr(), o["step_count"].data_ptr(),
+        o["key_out"].data_ptr(), o["sweeps"].data_ptr(), _stream(dev)),
+        "rbg_seed_extension_generate")
+    return o
+
+
 def uniform_generate(keys: torch.Tensor, m: int, N: int) -> StateBufs:
     keys = check_keys(keys)
     B, dev = keys.shape[0], keys.device

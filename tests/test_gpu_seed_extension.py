@@ -1,0 +1,177 @@
+"""GPU parity tests of SeedExtension (BASELINE configs[4]): the HIP path
+through the C-ABI against the reference's executed notebook and against the CPU oracle
+(oracle/seed_extension.c), bit-exact.
+
+Pinned by the reference: the 100-board batch of profiling_generators.ipynb cell 23 (defaults).
+Parity unpinned (oracle <-> HIP only): randomness > 0, two_sided=False, extension_iterations > 1
+and the solved boards (optimise_wire never moves an endpoint, so no golden of the reference sees
+it); the single-board cell 10 of the notebook is stale (see tests/test_oracle_goldens.py).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_dicts_equal, to_np
+
+pytestmark = pytest.mark.gpu
+
+WINDOW = [0, 1, 2, 7, 8, 9]
+WINDOW_BOARDS = [0, 1, 2, 97, 98, 99]
+
+
+@pytest.fixture(scope="module")
+def rbg():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (there is no CPU fallback to hide behind)")
+    import routing_board_generation_amd as pkg
+
+    pkg._native.lib()
+    return pkg
+
+
+def _keys(rbg, seed, B):
+    return rbg.split(rbg.PRNGKey(seed), B)
+
+
+def _compare(out, est, esolved, esweeps, what):
+    got = {"grid": to_np(out["train_grid"]), "start": to_np(out["start"]),
+           "target": to_np(out["target"]), "position": to_np(out["position"]),
+           "key": to_np(out["key_out"]), "step_count": to_np(out["step_count"])}
+    assert (to_np(out["sweeps"]) == esweeps).all(), f"{what}: sweep counts differ"
+    assert_dicts_equal(got, est, what + ": ")
+    if "solved_grid" in out:
+        bad = np.argwhere((to_np(out["solved_grid"]) != esolved).any((1, 2))).ravel()
+        assert bad.size == 0, f"{what}: solved boards differ, first {bad[:5].tolist()}"
+
+
+def test_seed_extension_batch100_golden(rbg, goldens):
+    """profiling_generators.ipynb cell 23: vmap(SeedExtensionGenerator(10, 5).__call__) over
+    split(PRNGKey(0), 100) -- all printed starts, targets, keys and grid windows."""
+    b = goldens["notebook"]["batch100_10x10_5_split_PRNGKey0"]["seed_extension"]
+    gen = rbg.SeedExtensionGenerator(10, 5)
+    assert rbg.RandomSeedGenerator is rbg.SeedExtensionGenerator  # the notebook's name for it
+    state = gen(_keys(rbg, 0, 100))
+    assert (to_np(state.key) == np.asarray(b["key"], np.uint32)).all()
+    assert (to_np(state.agents.start) == np.asarray(b["start"])).all()
+    assert (to_np(state.agents.target) == np.asarray(b["target"])).all()
+    assert (to_np(state.agents.position) == np.asarray(b["position"])).all()
+    win = to_np(state.grid)[np.ix_(WINDOW_BOARDS, WINDOW, WINDOW)]
+    assert (win == np.asarray(b["grid_window"])).all()
+    assert (to_np(state.step_count) == 0).all()
+    # a single key gives the same board as its row of the batch
+    one = gen(_keys(rbg, 0, 100)[7])
+    assert one.grid.shape == (10, 10)
+    assert (to_np(one.agents.start) == np.asarray(b["start"][7])).all()
+
+
+def test_seed_extension_c5_full_size(rbg, oracle):
+    """BASELINE configs[4]: SeedExtension 16x16, 10 agents, batch 4096, generator defaults."""
+    from routing_board_generation_amd import ops
+
+    keys = _keys(rbg, 0, 4096)
+    out = ops.seed_extension_generate(keys, 16, 10, split_first=True, want_solved=True)
+    est, esolved, esweeps = oracle.seed_extension_batch(to_np(keys), 16, 10, threads=16)
+    _compare(out, est, esolved, esweeps, "C5 seed extension")
+    assert esweeps.max() > 25  # the batch has its stragglers
+
+
+@pytest.mark.parametrize("m,N,B,seed,kw", [
+    (10, 5, 256, 1, dict(randomness=1.0, two_sided=False)),   # BoardDatasetGeneratorJAX defaults
+    (10, 5, 256, 2, dict(randomness=0.85, extension_iterations=3)),
+    (10, 5, 64, 3, dict(randomness=0.5, extension_iterations=21)),  # examples/online_randomseed_*
+    (8, 16, 128, 4, dict(randomness=0.3)),                    # every seed cell taken, LPB 16
+    (8, 5, 100, 5, dict()),
+    (12, 20, 64, 6, dict(randomness=0.2, extension_iterations=2)),  # LPB 32
+    (16, 40, 32, 7, dict(extension_iterations=2)),            # LPB 64
+    (16, 64, 16, 8, dict(randomness=0.7)),                    # N = 64, every seed cell taken
+    (5, 2, 64, 9, dict(extension_iterations=2)), (7, 4, 64, 10, dict(randomness=0.4)),
+    (2, 1, 16, 11, dict()), (3, 1, 16, 12, dict(extension_iterations=2)),
+    (16, 10, 128, 13, dict(extension_steps=2, extension_iterations=2)),
+    (16, 10, 64, 14, dict(extension_steps=2.5)), (16, 10, 33, 15, dict(extension_iterations=0)),
+    (32, 20, 64, 16, dict()), (40, 30, 8, 17, dict(randomness=0.1)),
+    (20, 10, 37, 18, dict(two_sided=False)),
+])
+def test_seed_extension_matches_oracle(rbg, oracle, m, N, B, seed, kw):
+    from routing_board_generation_amd import ops
+
+    keys = _keys(rbg, seed, B)
+    out = ops.seed_extension_generate(keys, m, N, split_first=True, want_solved=True, **kw)
+    est, esolved, esweeps = oracle.seed_extension_batch(to_np(keys), m, N, threads=16, **kw)
+    _compare(out, est, esolved, esweeps, f"seed extension {m}x{m}/{N} {kw}")
+    # without the solved board the last re-routing pass is skipped: same State
+    out2 = ops.seed_extension_generate(keys, m, N, split_first=True, want_solved=False, **kw)
+    _compare(out2, est, esolved, esweeps, f"seed extension (no solved) {m}x{m}/{N} {kw}")
+
+
+def test_seed_extension_board_api(rbg, oracle):
+    """SeedExtensionBoard methods (seed_extension.py:93-304) and the registry entry
+    (interface/board_generator_interface.py:64)."""
+    cls = rbg.BoardGenerator.get_board_generator(rbg.BoardName("offline_seed_extension"))
+    assert cls is rbg.SeedExtensionBoard
+    board = cls(10, 10, 5)
+    keys = _keys(rbg, 21, 50)
+    kw = dict(randomness=0.6, two_sided=True, extension_iterations=2, extension_steps=1e23)
+    est, esolved, _ = oracle.seed_extension_batch(to_np(keys), 10, 5, split_first=False,
+                                                  threads=8, **kw)
+    solved = board.return_solved_board(keys, **kw)
+    assert (to_np(solved) == esolved).all()
+    train = board.return_training_board(keys, **kw)
+    assert (to_np(train) == est["grid"]).all()
+    (sr, sc), (er, ec) = board.generate_starts_ends(keys, **kw)
+    assert (to_np(sr) == est["start"][..., 0]).all() and (to_np(sc) == est["start"][..., 1]).all()
+    assert (to_np(er) == est["target"][..., 0]).all() and (to_np(ec) == est["target"][..., 1]).all()
+    (sr1, _), _ = board.generate_starts_ends(keys[4], **kw)
+    assert sr1.shape == (5,) and (to_np(sr1) == est["start"][4, :, 0]).all()
+    # return_seeded_board(seedkey): what return_solved_board builds from split(key)[1]
+    seedkeys = rbg.split(keys, 2)[:, 1].contiguous()
+    seeded = board.return_seeded_board(seedkeys)
+    _, eseeded, _ = oracle.seed_extension_batch(to_np(keys), 10, 5, split_first=False,
+                                                extension_iterations=0)
+    assert (to_np(seeded) == eseeded).all()
+    with pytest.raises(ValueError):
+        rbg.SeedExtensionBoard(10, 10, 26)
+
+
+def test_seed_extension_dataset_generator(rbg, oracle):
+    """BoardDatasetGeneratorJAX with its reference defaults (board_name="offline_seed_extension",
+    randomness=1, two_sided=False; dataset_generator_jax.py:20-63) and make_online_generator."""
+    from routing_board_generation_amd.interface.board_generator_interface import \
+        make_online_generator
+
+    n, m, N = 200, 10, 5
+    gen = rbg.BoardDatasetGeneratorJAX(m, N, number_of_boards=n, generate_solved_boards=True)
+    est, esolved, _ = oracle.seed_extension_batch(
+        oracle.split(oracle.prng_key(0), n), m, N, split_first=False, randomness=1.0,
+        two_sided=False, threads=8)
+    assert (to_np(gen.heads) == est["start"].transpose(0, 2, 1)).all()
+    assert (to_np(gen.targets) == est["target"].transpose(0, 2, 1)).all()
+    assert (to_np(gen.solved_boards) == esolved).all()
+    keys = _keys(rbg, 5, 64)
+    state = gen(keys)
+    dst, which = oracle.dataset_sample_batch(to_np(keys), est["start"], est["target"], m)
+    assert (to_np(state.grid) == dst["grid"]).all() and (to_np(state.key) == dst["key"]).all()
+    assert (to_np(gen.print_board(int(which[0]))) == dst["grid"][0]).all()
+    g2 = make_online_generator("offline_seed_extension", m, N, randomness=0, two_sided=True,
+                               extension_iterations=1, extension_steps=1e23, number_of_boards=32)
+    est2, _, _ = oracle.seed_extension_batch(oracle.split(oracle.prng_key(0), 32), m, N,
+                                             split_first=False)
+    assert (to_np(g2.heads) == est2["start"].transpose(0, 2, 1)).all()
+    g3 = make_online_generator("online_random_seed", m, N)
+    assert isinstance(g3, rbg.SeedExtensionGenerator)
+    env = rbg.Connector(generator=g3)
+    st, ts = env.reset(keys[:8])
+    est3, _, _ = oracle.seed_extension_batch(to_np(keys[:8]), m, N)
+    assert (to_np(st.grid) == est3["grid"]).all() and ts.observation.grid.shape == (8, N, m, m)
+
+
+def test_seed_extension_argument_errors(rbg):
+    from routing_board_generation_amd import _native, ops
+
+    keys = _keys(rbg, 0, 4)
+    with pytest.raises(_native.NativeLibraryError):
+        ops.seed_extension_generate(keys, 10, 26, split_first=True)  # 25 seed cells
+    with pytest.raises(_native.NativeLibraryError):
+        ops.seed_extension_generate(keys, 10, 5, split_first=True, extension_iterations=-2)
+    out = ops.seed_extension_generate(keys[:0], 10, 5, split_first=True)
+    assert out["start"].shape == (0, 5, 2)
