@@ -307,12 +307,14 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
           if (need_try) {
             uint32_t idx;
             if (pos < n + kSeMargin) {
-              idx = idxb[pos];
+              idx = idxb[pos] & 3u;
             } else {
               idx = se_idx_after(K.a, K.b, pos - n);
             }
-            if ((okm >> idx) & 1u) {
-              chosen = (int)idx;
+            // (a valid direction comes up with probability >= 1/4 per try; the cap only keeps a
+            // corrupted stream from spinning forever: 0.75^512 < 1e-63)
+            if (((okm >> idx) & 1u) || pos - s >= 512) {
+              chosen = ((okm >> idx) & 1u) ? (int)idx : __builtin_ctz(okm);
               need_try = false;
             }
             ++pos;
