@@ -137,9 +137,12 @@ def all_configs():
         if kind == "prw":
             f = lambda: ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_state=True)  # noqa
             cf = lambda: O.generate_batch(keys.cpu().numpy(), m, N, threads=threads, want_solved=False)  # noqa
-        else:
+        elif kind == "seq":
             f = lambda: ops.seq_rw_generate(keys, m, N, split_first=True, want_solved=False)  # noqa
             cf = lambda: O.seq_rw_generator_batch(keys.cpu().numpy(), m, N, threads=threads)  # noqa
+        else:  # SeedExtensionGenerator.__call__ (reference defaults)
+            f = lambda: ops.seed_extension_generate(keys, m, N, split_first=True)  # noqa
+            cf = lambda: O.seed_extension_batch(keys.cpu().numpy(), m, N, threads=threads)  # noqa
         us = timed(f, 20 if B >= 1024 else 50)
         cf()
         rows.append({"config": name, "grid": m, "agents": N, "batch": B, "us_per_launch": us,
@@ -150,6 +153,9 @@ def all_configs():
     gen_row("C2 ParallelRandomWalk 16x16/10 B=4096", 16, 10, 4096)
     gen_row("C4 ParallelRandomWalk 32x32/20 B=4096 (one GPU's shard of 32768)", 32, 20, 4096)
     gen_row("C5 SequentialRandomWalk 16x16/10 B=4096", 16, 10, 4096, kind="seq")
+    gen_row("C5 SeedExtension 16x16/10 B=4096", 16, 10, 4096, kind="seed_ext")
+    gen_row("ref SeedExtension 10x10/5 B=100 (notebook batch: 427 ms on JAX-CPU)", 10, 5, 100,
+            kind="seed_ext")
     gen_row("ref ParallelRandomWalk 10x10/5 B=100 (notebook batch: 19.7 ms on JAX-CPU)", 10, 5, 100)
 
     # C3: env.step rollout, per-step API and fused

@@ -56,26 +56,51 @@ struct SeParams {
 };
 
 // extra LDS words per board after the slab of rbg_device.h:
-//   extension: idx bytes [n + margin] + rnd bytes [n];  seeding: nc sort keys;
+//   extension: idx bytes [4 + n + margin] + rnd bytes [4 + n + margin + 4] (the byte pointers of
+//   phase A run from two positions before to a few past their arrays);  seeding: nc sort keys;
 //   BFS: claim words [padded board] + FIFO u16 [n + 2]
 __host__ __device__ inline int se_extra_words(int words_padded, int n) {
   const int bfs = ((words_padded + 3) & ~3) + (n + 2 + 1) / 2;
-  const int ext = (2 * n + kSeMargin + 3) / 4;
+  const int ext = (2 * (n + kSeMargin) + 12 + 3) / 4;
   return (((bfs > ext ? bfs : ext) + 3) & ~3) + 4;
 }
 
-// DPP moves inside a row of 16 lanes (gfx9 dpp_ctrl encodings)
-__device__ __forceinline__ uint32_t dpp_quad_bcast0(uint32_t v) {  // quad_perm:[0,0,0,0]
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t dpp_quad_bcast1(uint32_t v) {  // quad_perm:[1,1,1,1]
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t dpp_row_shr3(uint32_t v) {  // lane i <- lane i - 3
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t dpp_row_shr4(uint32_t v) {  // lane i <- lane i - 4
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+// ---------------------------------------------------------------------------------------------
+// Phase A: `count` links of the sweep's key chain.  Lane roles (sub-lane, all in the first row of
+// 16 lanes), one Threefry evaluation per link for all of them:
+//   0,1  the chain itself: blocks (0,2),(1,3) of split(K_s) -> K_{s+1} (y0), choice key C_s (y1)
+//   4,5  blocks (0,2),(1,3) of split(C_{s-1})            -> its second child D_{s-1} (y1)
+//   6    random_bits(C_{s-1}, ()) -> uniform of cell s-1  (use_random byte, kRnd only)
+//   8    random_bits(D_{s-2}, ()) -> direction number of chain position s-2 (idx byte)
+// Operands move by DPP (gfx9 dpp_ctrl encodings): row_shr:4 hands the y1 pair of a quad to the
+// next quad, quad_perm broadcasts lane 0 / lane 1 of the quad, and a bank-masked second move
+// gives quad 0 its y0 pair -- five moves, no selects, no LDS on the chain.
+// Every lane stores one byte per link through its own running pointer (increment 1 for the lane
+// whose byte is wanted, 0 for the others, which keep hitting their private dump byte): no
+// exec-mask branches in the loop.
+// ---------------------------------------------------------------------------------------------
+template <bool kRnd>
+__device__ __forceinline__ void se_chain_links(Key2 &ck, uint32_t cx0, uint32_t cx1, int count,
+                                               uint8_t *&idx_ptr, int idx_inc, uint8_t *&rnd_ptr,
+                                               int rnd_inc, float randomness) {
+#pragma unroll 1
+  for (int s = 0; s < count; ++s) {
+    uint32_t y0, y1;
+    threefry(ck.a, ck.b, cx0, cx1, y0, y1);
+    const int sh = __builtin_amdgcn_update_dpp(0, (int)y1, 0x114, 0xF, 0xF, true);  // row_shr:4
+    int a = __builtin_amdgcn_update_dpp(0, sh, 0x00, 0xF, 0xF, true);   // quad_perm:[0,0,0,0]
+    int b = __builtin_amdgcn_update_dpp(0, sh, 0x55, 0xF, 0xF, true);   // quad_perm:[1,1,1,1]
+    a = __builtin_amdgcn_update_dpp(a, (int)y0, 0x00, 0xF, 0x1, false);  // lanes 0..3 of the row
+    b = __builtin_amdgcn_update_dpp(b, (int)y0, 0x55, 0xF, 0x1, false);
+    ck.a = (uint32_t)a;
+    ck.b = (uint32_t)b;
+    *idx_ptr = (uint8_t)y0;  // low two bits = the direction number (masked by the reader)
+    idx_ptr += idx_inc;
+    if (kRnd) {
+      *rnd_ptr = (uint8_t)(randomness > bits_to_uniform(y0));
+      rnd_ptr += rnd_inc;
+    }
+  }
 }
 
 // min over the sub-wave, result in every lane
@@ -189,12 +214,12 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
     wave_lds_fence();
   }
 
-  uint8_t *idxb = reinterpret_cast<uint8_t *>(xtra);  // [n + margin] direction number per position
-  uint8_t *rndb = idxb + n + kSeMargin;               // [n] use_random per cell
-  // lane roles of the phase-A evaluation (sub-lane): 0,1 the chain (blocks (0,2),(1,3) of
-  // split(K)); 2,3 split(choice key); 4 uniform(choice key); 6 random_bits(split(choice key)[1])
-  const uint32_t cx0 = l < 2 ? (uint32_t)l : l < 4 ? (uint32_t)(l - 2) : 0u;
-  const uint32_t cx1 = l < 4 ? cx0 + 2u : 0u;
+  uint8_t *idxb = reinterpret_cast<uint8_t *>(xtra) + 4;  // [n + margin] direction number per position
+  uint8_t *rndb = idxb + n + kSeMargin + 4;               // [n] use_random per cell
+  uint8_t *dump = reinterpret_cast<uint8_t *>(scr + l);   // this lane's private dump byte
+  // counters of this lane's role in the phase-A evaluation (se_chain_links)
+  const uint32_t cx0 = (l == 1 || l == 5) ? 1u : 0u;
+  const uint32_t cx1 = (l < 2 || l == 4 || l == 5) ? cx0 + 2u : 0u;
 
   int total_sweeps = 0;
   for (int it = 0; it < p.iterations; ++it) {
@@ -232,21 +257,21 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
       const bool flop = randint_pow2(sw, pk, 1u) == 0u;
 
       // ---- phase A: the sweep's chain --------------------------------------------------------
-      Key2 ck = K;  // lanes 0,1: K_s; lanes 2..4: choice key of s-1; lane 6: its second child
-      Key2 kn = K;
-#pragma unroll 1
-      for (int s = 0; s < n + kSeMargin + 2; ++s) {
-        uint32_t y0, y1;
-        threefry(ck.a, ck.b, cx0, cx1, y0, y1);
-        const uint32_t qa0 = dpp_quad_bcast0(y0), qb0 = dpp_quad_bcast1(y0);
-        const uint32_t qa1 = dpp_quad_bcast0(y1), qb1 = dpp_quad_bcast1(y1);
-        const uint32_t sa = dpp_row_shr4(y1), sb = dpp_row_shr3(y1);
-        ck.a = l < 2 ? qa0 : l < 4 ? qa1 : sa;
-        ck.b = l < 2 ? qb0 : l < 4 ? qb1 : sb;
-        if (s == n - 1) kn = ck;  // lanes 0,1 now hold K_n, the key the next sweep starts from
-        if (l == 6 && s >= 2) idxb[s - 2] = (uint8_t)(y0 & 3u);
-        if (p.rnd_mode == 2 && l == 4 && s >= 1 && s <= n)
-          rndb[s - 1] = (uint8_t)(p.randomness > bits_to_uniform(y0));
+      Key2 ck = K;
+      // lane 8's byte of link s is the direction number of position s - 2, lane 6's the
+      // use_random bit of cell s - 1
+      uint8_t *ip = l == 8 ? idxb - 2 : dump, *rp = l == 6 ? rndb - 1 : dump;
+      const int ii = l == 8 ? 1 : 0, ri = l == 6 ? 1 : 0;
+      if (p.rnd_mode == 2) {
+        se_chain_links<true>(ck, cx0, cx1, n, ip, ii, rp, ri, p.randomness);
+      } else {
+        se_chain_links<false>(ck, cx0, cx1, n, ip, ii, rp, ri, p.randomness);
+      }
+      const Key2 kn = ck;  // lanes 0,1 now hold K_n, the key the next sweep starts from
+      if (p.rnd_mode == 2) {
+        se_chain_links<true>(ck, cx0, cx1, kSeMargin + 2, ip, ii, rp, ri, p.randomness);
+      } else {
+        se_chain_links<false>(ck, cx0, cx1, kSeMargin + 2, ip, ii, rp, ri, p.randomness);
       }
       K.a = sw.bcast(kn.a, 0);
       K.b = sw.bcast(kn.b, 0);
