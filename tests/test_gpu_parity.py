@@ -109,6 +109,45 @@ def test_batch100_generators_golden(rbg, goldens, name):
     assert (win == np.asarray(b["grid_window"])).all()
 
 
+# ------------------------------------------------------------------------------ C1 vectors
+# the two 8x8 / 5-agent boards of BASELINE configs[0], derived by the
+# survey's independent emulation (which reproduces the reference goldens G1-G7).
+B1_SINGLE = dict(
+    key_in=(0, 0), state_key=(4146024105, 967050713), T=9,
+    start=[[4, 3], [5, 7], [3, 5], [2, 1], [3, 0]], target=[[0, 5], [7, 3], [0, 6], [2, 3], [6, 0]],
+    solved=[[10, 10, 10, 0, 0, 3, 9, 7], [10, 0, 10, 10, 1, 1, 0, 7], [10, 11, 0, 12, 1, 0, 7, 7],
+            [14, 0, 0, 1, 1, 8, 7, 0], [13, 13, 0, 2, 0, 0, 0, 0], [0, 13, 13, 0, 0, 0, 0, 5],
+            [15, 0, 13, 4, 4, 4, 4, 4], [13, 13, 13, 6, 0, 0, 0, 0]])
+B1_BATCH1 = dict(
+    key_in=(928981903, 3453687069), state_key=(3152301319, 4230269698), T=12,
+    start=[[2, 6], [6, 7], [4, 7], [0, 4], [3, 1]], target=[[3, 7], [6, 3], [6, 1], [0, 7], [7, 7]],
+    solved=[[0, 0, 0, 0, 11, 10, 0, 12], [0, 0, 0, 0, 0, 10, 10, 10], [0, 0, 0, 0, 0, 0, 2, 1],
+            [0, 14, 0, 0, 7, 7, 7, 3], [13, 13, 0, 0, 7, 0, 7, 8], [13, 0, 7, 7, 7, 4, 4, 4],
+            [13, 9, 7, 6, 4, 4, 0, 5], [13, 13, 13, 13, 13, 13, 13, 15]])
+
+
+@pytest.mark.parametrize("vec", [B1_SINGLE, B1_BATCH1], ids=["PRNGKey0", "split_PRNGKey0_1"])
+def test_c1_boards_of_survey_appendix_b1(rbg, oracle, torch_mod, vec):
+    from routing_board_generation_amd import ops
+
+    if vec is B1_BATCH1:  # keys = split(PRNGKey(0), 1)
+        assert tuple(to_np(_keys(rbg, 0, 1))[0].tolist()) == vec["key_in"]
+    key = torch_mod.tensor([vec["key_in"]], dtype=torch_mod.uint32, device="cuda")
+    out = ops.prw_generate(key, 8, 5, split_first=True, want_solved=True, want_train=True,
+                           want_iters=True)
+    st, solved, iters = oracle.generate_batch(np.asarray([vec["key_in"]], np.uint32), 8, 5)
+    for got_solved, got_start, got_target, got_key, got_T in (
+            (to_np(out["solved_grid"])[0], to_np(out["start"])[0], to_np(out["target"])[0],
+             to_np(out["key_out"])[0], int(to_np(out["iters"])[0])),
+            (solved[0], st["start"][0], st["target"][0], st["key"][0], int(iters[0]))):
+        assert (got_solved == np.asarray(vec["solved"])).all()
+        assert got_start.tolist() == vec["start"] and got_target.tolist() == vec["target"]
+        assert tuple(got_key.tolist()) == vec["state_key"] and got_T == vec["T"]
+    train = np.asarray(vec["solved"]).copy()
+    train[train % 3 == 1] = 0
+    assert (to_np(out["train_grid"])[0] == train).all()
+
+
 # ------------------------------------------------------------------------------ oracle parity
 CONFIGS = [
     # (m, N, B, seed)          BASELINE configs: C1 8x8/5/B=1, C2 16x16/10/4096, C4 shape 32x32/20
@@ -198,7 +237,8 @@ def test_ragged_batch_sizes(rbg, oracle, B, torch_mod):
 
 
 # ------------------------------------------------------------------------------ Connector
-@pytest.mark.parametrize("m,N,B", [(16, 10, 256), (10, 5, 100), (7, 4, 19), (32, 20, 32)])
+@pytest.mark.parametrize("m,N,B", [(16, 10, 256), (10, 5, 100), (7, 4, 19), (32, 20, 32),
+                                   (12, 33, 24), (16, 64, 12), (10, 32, 16)])
 def test_connector_reset_matches_oracle(rbg, oracle, m, N, B):
     env = rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N))
     keys = _keys(rbg, 2, B)
@@ -221,7 +261,10 @@ def test_connector_reset_single_env_shapes(rbg, oracle):
 
 
 @pytest.mark.parametrize("auto_reset", [False, True])
-@pytest.mark.parametrize("m,N,B,steps", [(16, 10, 128, 60), (10, 5, 64, 60), (7, 4, 21, 25)])
+@pytest.mark.parametrize("m,N,B,steps", [(16, 10, 128, 60), (10, 5, 64, 60), (7, 4, 21, 25),
+                                         # N >= 32: regenerate() takes the two- and three-
+                                         # evaluation Threefry paths inside the env kernels
+                                         (12, 33, 24, 45), (16, 64, 12, 45), (14, 40, 16, 45)])
 def test_connector_rollout_matches_oracle(rbg, oracle, torch_mod, m, N, B, steps, auto_reset):
     """Random-legal-action rollout: state and timestep are compared after EVERY step, through
     connection events, collisions, blocked agents, the time limit and (auto_reset) fused resets."""
@@ -335,7 +378,8 @@ def test_registry(rbg):
 # ------------------------------------------------------------------------------ fused rollout
 @pytest.mark.parametrize("auto_reset", [False, True])
 @pytest.mark.parametrize("m,N,B,steps", [(16, 10, 128, 45), (10, 5, 64, 45), (7, 4, 21, 30),
-                                         (32, 20, 16, 25)])
+                                         (32, 20, 16, 25), (12, 33, 24, 40), (16, 64, 12, 40),
+                                         (14, 40, 16, 40)])
 def test_random_rollout_matches_oracle(rbg, oracle, m, N, B, steps, auto_reset):
     """rbg_connector_rollout == steps x { rbg_random_actions; rbg_connector_step }: final state,
     per-env counters and the timestep of the last step, against the oracle's step-by-step loop."""
@@ -423,7 +467,8 @@ def test_sequential_random_walk_golden(rbg, goldens):
     assert (to_np(state.key) == np.asarray(s["key"], np.uint32)).all()
 
 
-@pytest.mark.parametrize("m,N,B,seed", [(16, 10, 512, 0), (10, 5, 100, 0), (7, 4, 64, 1),
+@pytest.mark.parametrize("m,N,B,seed", [(16, 10, 4096, 0),  # BASELINE configs[4], full size
+                                        (10, 5, 100, 0), (7, 4, 64, 1),
                                         (4, 7, 128, 1), (3, 2, 33, 2), (5, 6, 40, 3),
                                         (32, 20, 32, 4), (6, 3, 17, 5)])
 def test_sequential_random_walk_matches_oracle(rbg, oracle, m, N, B, seed):
@@ -810,8 +855,9 @@ def test_random_agent_loop_example_runs():
     assert int(lines[1].split(" GPU(s), ")[1].split(" episodes")[0]) > 256, out
 
 
-@pytest.mark.parametrize("m,N,B,steps,tl", [(16, 10, 2048, 120, 50), (8, 5, 4096, 100, 12),
-                                            (12, 7, 1024, 90, 25), (32, 20, 256, 80, 40)])
+@pytest.mark.parametrize("m,N,B,steps,tl", [(16, 10, 4096, 110, 50),  # BASELINE configs[2], full size
+                                            (8, 5, 4096, 100, 12), (12, 7, 1024, 90, 25),
+                                            (32, 20, 256, 80, 40), (12, 33, 96, 60, 20)])
 def test_long_auto_reset_rollouts_match_oracle(rbg, oracle, m, N, B, steps, tl):
     """Many envs over several episodes each (default wrapper: stash + refills): state and
     timestep against the oracle after every step."""

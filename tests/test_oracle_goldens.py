@@ -355,3 +355,21 @@ def test_randint_matches_scalar_form(oracle):
         k = oracle.split(oracle.prng_key(s))[1]
         for span in (2, 4, 7, 100, 65537):
             assert int(oracle.randint_vec(k, 1, 0, span)[0]) == oracle.randint(k, 0, span)
+
+
+def test_c1_boards_of_survey_appendix_b1(oracle):
+    """SURVEY.md Appendix B.1 (BASELINE configs[0], 8x8 / 5 agents): the board for PRNGKey(0) and
+    the B = 1 batch form, from the survey's independent emulation."""
+    st, solved, iters = oracle.generate_batch(np.asarray([[0, 0]], np.uint32), 8, 5)
+    assert st["key"][0].tolist() == [4146024105, 967050713] and int(iters[0]) == 9
+    assert st["start"][0].tolist() == [[4, 3], [5, 7], [3, 5], [2, 1], [3, 0]]
+    assert st["target"][0].tolist() == [[0, 5], [7, 3], [0, 6], [2, 3], [6, 0]]
+    assert solved[0][0].tolist() == [10, 10, 10, 0, 0, 3, 9, 7]
+    assert solved[0][7].tolist() == [13, 13, 13, 6, 0, 0, 0, 0]
+    keys = oracle.split(oracle.prng_key(0), 1)
+    assert keys[0].tolist() == [928981903, 3453687069]
+    st, solved, iters = oracle.generate_batch(keys, 8, 5)
+    assert st["key"][0].tolist() == [3152301319, 4230269698] and int(iters[0]) == 12
+    assert st["start"][0].tolist() == [[2, 6], [6, 7], [4, 7], [0, 4], [3, 1]]
+    assert st["target"][0].tolist() == [[3, 7], [6, 3], [6, 1], [0, 7], [7, 7]]
+    assert solved[0][7].tolist() == [13, 13, 13, 13, 13, 13, 13, 15]
