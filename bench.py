@@ -10,6 +10,14 @@ over 4096 keys per GPU (BASELINE.json configs[1]), producing the full Connector 
 Keys are `split(PRNGKey(0), 4096 * n_gpus)` sharded contiguously over the ranks (weak scaling:
 per-GPU work is fixed), already resident in HBM when the timed region starts.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the torchrun
+command above itself, as a CHILD process (before anything here has touched the GPU), and relays
+rank 0's line and the child's exit code.
+
+`--mode step-replay` and `--mode stream` run ONE launch population each (the recorded-action
+replay of connector_step_kernel at B = 4096, the B = 65536 NOOP stream) and print only the
+env_step part: what the rocprofv3 passes under profiles/ are taken from.
+
 Rank 0 prints ONE JSON line.  Besides the driver contract it carries
   roofline      achieved algorithmic GB/s of the dominant kernel (prw_generate_kernel) against the
                 HBM peak, from HIP-event durations measured live around every launch
@@ -78,8 +86,125 @@ def host_cpu_share() -> int:
     return min(n, 64)
 
 
+def host_cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def measured_issue(kernel: str, boards: int):
+    """VALU wave-instructions per launch from the committed SQ counter pass
+    (profiles/*_issue.json, tools/summarize_profile.py); B = 4096, 16x16/10 only."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue.json")))
+    if not files or boards != BATCH_PER_GPU:
+        return None
+    for name, rec in json.load(open(files[-1]))["kernels"].items():
+        if name == kernel or name.startswith(kernel + "<"):
+            return rec
+    return None
+
+
+SIMDS, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2  # 256 CUs x 4 SIMD-32; a wave64 VALU op = 2 passes
+
+
+def issue_roofline(kernel: str, boards: int, kernel_avg_ms: float):
+    """The generator is issue-, not HBM-bound: its VALU wave-instructions against the rate at
+    which 1024 SIMD-32 units can issue them (one wave64 instruction per 2 cycles each)."""
+    rec = measured_issue(kernel, boards)
+    if rec is None:
+        return None
+    peak = SIMDS * CLOCK_HZ / VALU_CYCLES  # wave-instructions per second, whole chip
+    ach = rec["valu_insts_per_launch"] / (kernel_avg_ms * 1e-3)
+    return {"bound": "valu_issue", "achieved": ach / 1e12, "peak": peak / 1e12,
+            "unit": "T wave-instr/s", "frac": ach / peak,
+            "valu_wave_insts_per_launch": rec["valu_insts_per_launch"],
+            "floor_ms": rec["valu_insts_per_launch"] / peak * 1e3,
+            "note": "VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) / "
+                    "launch duration, against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 "
+                    "instruction; the launch also waits for its longest board (DESIGN.md 4.1)"}
+
+
+def copy_peak_gbs(dev) -> float:
+    """Measured HBM copy rate of this GPU (quoted beside the 8 TB/s spec figure):
+    a 1 GiB device-to-device copy kernel (torch's elementwise copy), read + written bytes."""
+    import torch
+
+    n = 1 << 28  # float32 elements = 1 GiB per buffer, far beyond the 256 MiB Infinity Cache
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / 10
+    del src, dst
+    return 2 * n * 4 / (ms * 1e-3) / 1e9
+
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int, argv) -> int:
+    """`bench.py --gpus N` (N > 1) outside a launcher: start the one-process-per-GPU job as a
+    CHILD (this parent has not imported torch.cuda or made any HIP call, and never replaces
+    itself: an exec from a GPU-initialised process is not allowed on this pool) and relay its
+    output and exit code.  Rank 0 of the child prints the JSON line straight to our stdout."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse_launch(args) -> None:
+    """CPU-only rehearsal of the multi-rank plumbing (tests/test_bench_launch.py): gloo ranks
+    shard the keys' index range, meet at the barriers, all-reduce a metrics vector and rank 0
+    prints a line of the driver's shape with no measurement in it."""
+    import torch.distributed as dist
+
+    from routing_board_generation_amd import sharding
+
+    rank, _, world = sharding.init_distributed(backend="gloo", single_device=True)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+    lo, hi = sharding.shard_bounds(BATCH_PER_GPU * world, rank, world)
+    if dist.is_initialized():
+        dist.barrier()
+    red = sharding.all_reduce_metrics({"boards": float((hi - lo) * args.steps),
+                                       "elapsed_s": 1.0 + rank})
+    if rank == 0:
+        print(json.dumps({"metric": "boards_per_sec", "value": None, "unit": "boards/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "rehearsal": True, "boards": red["boards"],
+                          "elapsed_s_max_over_ranks": red["elapsed_s"], "scaling": "weak"}),
+              flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def cpu_baseline(sample_batches: int):
-    """Oracle (CPU port of the reference algorithm) on the same workload, all host threads."""
+    """Oracle (CPU port of the reference algorithm) on the same workload: all host threads and a
+    single thread, plus the reference's own published case (10x10/5, batch 100) on this host."""
     import numpy as np  # noqa: F401
 
     from oracle import oracle as O
@@ -93,10 +218,38 @@ def cpu_baseline(sample_batches: int):
     O.generate_batch(keys, GRID, AGENTS, threads=threads, want_solved=False)  # ONE parallel region
     dt = time.perf_counter() - t0
     boards = sample_batches * BATCH_PER_GPU
+    t0 = time.perf_counter()
+    O.generate_batch(keys[:2 * BATCH_PER_GPU], GRID, AGENTS, threads=1, want_solved=False)
+    dt1 = time.perf_counter() - t0
+    # the reference's published case: 19.7 ms per vmapped batch of 100 boards at 10x10/5
+    k100 = O.split(O.prng_key(0), 100)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.generate_batch(k100, 10, 5, threads=threads, want_solved=False)
+    ms100 = (time.perf_counter() - t0) / reps * 1e3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.generate_batch(k100, 10, 5, threads=1, want_solved=False)
+    ms100_1 = (time.perf_counter() - t0) / reps * 1e3
     return {"value": boards / dt, "unit": "boards/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": 2 * BATCH_PER_GPU / dt1, "unit": "boards/s", "cores": 1,
+                              "sample": f"{2 * BATCH_PER_GPU} boards 16x16/10, {dt1:.2f} s"},
+            "host_cpu": host_cpu_model(),
             "sample": f"{boards} boards 16x16/10 (keys split(PRNGKey(0), {boards})) in one "
                       f"OpenMP region, {dt:.2f} s wall on {threads} threads "
-                      f"(~{dt * threads:.0f} core-seconds)"}
+                      f"(~{dt * threads:.0f} core-seconds)",
+            "reference_case_10x10_5_batch100": {
+                "cpu_port_ms_per_batch": ms100, "cpu_port_ms_per_batch_single_thread": ms100_1,
+                "published_ms_per_batch": 19.7,
+                "published_source": "package_evaluation/profiling_generators.ipynb, vmapped "
+                                    "jitted ParallelRandomWalkGenerator on JAX-CPU, hardware "
+                                    "unspecified"},
+            "note": "the port restates the reference's own formulation (N private grid copies "
+                    "per agent step, max-join, correction masks, a full stable sort per board) in "
+                    "plain C, because the JAX-CPU reference cannot run on this box; it is a "
+                    "reported baseline, and the GPU/CPU ratio is NOT a speed-up claim about the "
+                    "kernels -- the roofline fractions are"}
 
 
 def timed(fn, reps):
@@ -192,6 +345,38 @@ def all_configs():
 
 
 
+def pure_stream(rbg, ops, torch, dev, m, N, sb, Bs, copy_gbs=None):
+    """connector_step_kernel as a pure stream: NOOP actions (no env terminates), a batch large
+    enough to leave the Infinity Cache -- how close the kernel gets to the HBM roofline when
+    neither resets nor the launch shape limit it."""
+    skeys = rbg.split(rbg.PRNGKey(1, device=dev), Bs)
+    sst, sts = ops.connector_reset(skeys, m, N)
+    sso = ops.alloc_state(Bs, m, N, dev)
+    noop = torch.zeros((Bs, N), dtype=torch.int32, device=dev)
+    for _ in range(3):
+        ops.connector_step(sst, noop, time_limit=1 << 30, state_out=sso, timestep=sts)
+    pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    pe0.record()
+    for _ in range(20):
+        ops.connector_step(sst, noop, time_limit=1 << 30, state_out=sso, timestep=sts)
+    pe1.record()
+    torch.cuda.synchronize(dev)
+    p_ms = pe0.elapsed_time(pe1) / 20
+    p_ach = Bs * sb / (p_ms * 1e-3) / 1e9
+    if copy_gbs is None:
+        copy_gbs = copy_peak_gbs(dev)
+    return {"batch": Bs, "launches": 23, "kernel_avg_ms": p_ms, "achieved": p_ach, "unit": "GB/s",
+            "peak": HBM_PEAK_GBS, "frac": p_ach / HBM_PEAK_GBS,
+            "peak_measured_copy": copy_gbs, "frac_of_measured_copy": p_ach / copy_gbs,
+            "algorithmic_bytes_per_launch": Bs * sb,
+            "note": "connector_step_kernel, NOOP actions (no terminations), working set "
+                    f"{Bs * sb / 1e6:.0f} MB > 256 MiB Infinity Cache; 92 % of its bytes are "
+                    "write-once non-temporal stores, which is why it can exceed the measured "
+                    "COPY rate (a copy reads as many bytes as it writes); `bench.py --mode "
+                    "stream` runs only this and its WRITE_SIZE pass is in profiles/"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +401,12 @@ def main() -> None:
                     help="also time the K generator launches with three batches in flight on "
                          "three streams (off by default so that the rocprofv3 kernel statistics "
                          "of the default command describe lone launches only)")
+    ap.add_argument("--mode", choices=("all", "generator", "step-replay", "stream"), default="all",
+                    help="all = the driver's line; generator = the headline only; step-replay / "
+                         "stream = ONE launch population of connector_step_kernel each (the "
+                         "rocprofv3 passes under profiles/ are taken from these)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="developer option: CPU-only rehearsal of the multi-rank launch (gloo)")
     ap.add_argument("--all-configs", action="store_true",
                     help="measure every BASELINE.json config (GPU + CPU port) and print a JSON "
                          "list instead of the driver's line (profiles/*_configs.json)")
@@ -223,6 +414,16 @@ def main() -> None:
     if args.all_configs:
         all_configs()
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become the parent of the one-process-per-GPU job
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.rehearse_launch:
+        rehearse_launch(args)
+        return
+    if args.mode == "generator":
+        args.env_steps = args.rollout_steps = 0
+    elif args.mode in ("step-replay", "stream"):
+        args.steps, args.warmup, args.rollout_steps, args.cpu_sample = 1, 0, 0, 0
 
     import torch
     import torch.distributed as dist
@@ -296,8 +497,9 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": B * bpb,
                 "bytes_per_board": bpb, "boards_per_launch": B,
                 "kernel_avg_ms": kernel_avg_ms,
+                "issue": issue_roofline("prw_generate_kernel", B, kernel_avg_ms),
                 "note": "latency-bound walk (serial dependent iterations per board): HBM fraction "
-                        "reported for the record; see DESIGN.md"}
+                        "reported for the record, the issue-based figure beside it; see DESIGN.md"}
 
     pipelined = None
     if args.pipelined:
@@ -345,6 +547,7 @@ def main() -> None:
     #   fused_policy prefetch + policy and step in one launch (rbg_connector_rollout, 1 step)
     #   no_auto_reset  auto-reset off: finished envs stay terminal, no walk ever runs
     env_step = None
+    copy_gbs = copy_peak_gbs(dev) if (rank == 0 and args.mode != "generator") else None
     if args.env_steps > 0:
         sb = env_step_bytes(m, N)
 
@@ -395,9 +598,12 @@ def main() -> None:
             return em["env_steps"] / em["elapsed_s"]
 
         def step_kernel_ms(refill_every):
-            """Average duration of a step launch alone: the same trajectory replayed with the
-            actions of a recorded pass, so the timed stream holds connector_kernel launches only
-            (plus one refill per epoch); one event pair around the region."""
+            """Average duration of a connector_step_kernel launch alone: the same trajectory
+            replayed with the actions of a recorded pass, so the timed stream holds step launches
+            only.  HIP-event pairs bracket every run of consecutive step launches BETWEEN two
+            refill launches (the refill of an epoch is queued after its last step), so the refills
+            are outside the timed spans; the dependent-launch gaps inside a run are inside.
+            Returns (ms per step launch, ms per step with the refills amortised in)."""
             n = args.env_steps
             rec = torch.empty((n, B, N), dtype=torch.int32, device=dev)
             for replay in (False, True):
@@ -411,18 +617,52 @@ def main() -> None:
                         rec[t].copy_(loop.action)
                     loop.drain()
                     continue
+                ep, spans = loop._epochs, []
+                queue_refill = ep.after_launch
+
+                def after_launch(stream=None):
+                    due = ep.tick % ep.K == ep.K - 1
+                    if due:
+                        spans[-1][1].record()  # the run ends before the refill is queued
+                    queue_refill(stream)
+                    if due:
+                        spans.append([torch.cuda.Event(enable_timing=True),
+                                      torch.cuda.Event(enable_timing=True)])
+                        spans[-1][0].record()
+
+                ep.after_launch = after_launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                spans.append([torch.cuda.Event(enable_timing=True),
+                              torch.cuda.Event(enable_timing=True)])
                 torch.cuda.synchronize(dev)
                 e0.record()
+                spans[-1][0].record()
                 for t in range(n):
                     loop.step(t, action=rec[t])
                 e1.record()
+                spans[-1][1].record()  # closes the last (possibly empty) run
                 torch.cuda.synchronize(dev)
                 loop.drain()
-                return e0.elapsed_time(e1) / n
+                in_runs = sum(a.elapsed_time(b) for a, b in spans)
+                return in_runs / n, e0.elapsed_time(e1) / n
 
+        if args.mode == "step-replay":
+            k_step, k_span = step_kernel_ms(16)
+            ach = B * sb / (k_step * 1e-3) / 1e9
+            if rank == 0:
+                print(json.dumps({"mode": "step-replay", "kernel": "connector_step_kernel",
+                                  "launches": 2 * args.env_steps, "batch": B,
+                                  "kernel_avg_ms": k_step, "span_with_refills_ms": k_span,
+                                  "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                  "bytes_per_env_step": sb}), flush=True)
+            return
+        if args.mode == "stream":
+            print(json.dumps({"mode": "stream", "kernel": "connector_step_kernel",
+                              **pure_stream(rbg, ops, torch, dev, m, N, sb, args.stream_batch)}),
+                  flush=True)
+            return
         v_pref, k_pref = run_loop(16, False)
-        k_step = step_kernel_ms(16)
+        k_step, k_span = step_kernel_ms(16)
         v_inl, k_inl = run_loop(0, False)
         v_fus, k_fus = run_loop(16, True)
         v_off, k_off = run_loop(0, False, auto_reset=False)
@@ -434,6 +674,8 @@ def main() -> None:
                        "donate = State advanced in place + two alternating TimeStep buffers"}
         ach = B * sb / (k_step * 1e-3) / 1e9
         env_step = {"metric": "env_steps_per_sec", "value": v_pref, "unit": "env-steps/s",
+                    "parity": "unpinned (Connector.step semantics modelled on jumanji 0.2.2; no "
+                              "reference fixture exists for them)",
                     "steps": args.env_steps, "auto_reset": True,
                     "policy": "rbg_random_actions (masked uniform), one launch per step",
                     "variants": {"prefetch": v_pref, "inline_reset": v_inl,
@@ -441,43 +683,32 @@ def main() -> None:
                     "ms_per_step": {"prefetch": k_pref, "inline_reset": k_inl,
                                     "prefetch_fused_policy": k_fus, "no_auto_reset": k_off},
                     "wrapper_api": api,
-                    "roofline": {"bound": "hbm", "kernel": "connector_kernel", "achieved": ach,
+                    "roofline": {"bound": "hbm", "kernel": "connector_step_kernel",
+                                 "achieved": ach,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": measured_traffic("connector_kernel", B),
+                                 "peak_measured_copy": copy_gbs,
+                                 "frac_of_measured_copy": ach / copy_gbs if copy_gbs else None,
+                                 "traffic": measured_traffic("connector_step_kernel", B),
                                  "algorithmic_bytes_per_launch": B * sb,
                                  "bytes_per_env_step": sb, "kernel_avg_ms": k_step,
-                                 "note": "average duration of a connector_kernel step launch of "
+                                 "span_with_refills_ms": k_span,
+                                 "parity": "unpinned (Connector.step semantics modelled on "
+                                           "jumanji 0.2.2; no reference fixture, DESIGN.md 2)",
+                                 "note": "average duration of a connector_step_kernel launch of "
                                          "the prefetch variant: the rollout replayed with "
-                                         "recorded actions, so the timed stream holds step "
-                                         "launches only (event span / steps, launch gaps "
-                                         "included; one refill launch per 16 steps on the same stream); the "
-                                         "whole step incl. the policy launch is ms_per_step"}}
+                                         "recorded actions, HIP-event pairs around every run of "
+                                         "step launches between two refill launches (dependent-"
+                                         "launch gaps included, refills excluded; `bench.py "
+                                         "--mode step-replay` runs only this, and its rocprofv3 "
+                                         "kernel stats are in profiles/); span_with_refills_ms "
+                                         "amortises the one refill per 16 steps in; the whole "
+                                         "step incl. the policy launch is ms_per_step"}}
         # the same kernel as a pure stream (no env terminates, batch large enough to leave the
         # Infinity Cache): how close connector_kernel gets to the HBM roofline when neither resets
         # nor the host's launch rate limit it
         if rank == 0 and args.stream_batch > 0:
-            Bs = args.stream_batch
-            skeys = rbg.split(rbg.PRNGKey(1, device=dev), Bs)
-            sst, sts = ops.connector_reset(skeys, m, N)
-            sso = ops.alloc_state(Bs, m, N, dev)
-            noop = torch.zeros((Bs, N), dtype=torch.int32, device=dev)
-            for _ in range(3):
-                ops.connector_step(sst, noop, time_limit=1 << 30, state_out=sso, timestep=sts)
-            pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize(dev)
-            pe0.record()
-            for _ in range(20):
-                ops.connector_step(sst, noop, time_limit=1 << 30, state_out=sso, timestep=sts)
-            pe1.record()
-            torch.cuda.synchronize(dev)
-            p_ms = pe0.elapsed_time(pe1) / 20
-            p_ach = Bs * sb / (p_ms * 1e-3) / 1e9
-            env_step["pure_step_stream"] = {
-                "batch": Bs, "kernel_avg_ms": p_ms, "achieved": p_ach, "unit": "GB/s",
-                "peak": HBM_PEAK_GBS, "frac": p_ach / HBM_PEAK_GBS,
-                "note": "connector_kernel, NOOP actions (no terminations), working set "
-                        f"{Bs * sb / 1e6:.0f} MB > 256 MiB Infinity Cache"}
-            del sst, sts, sso, noop
+            env_step["pure_step_stream"] = pure_stream(rbg, ops, torch, dev, m, N, sb,
+                                                       args.stream_batch, copy_gbs)
 
     # ---------------------------------------------------------------- secondary: fused rollout
     rollout = None
@@ -518,6 +749,8 @@ def main() -> None:
         v_stash, ms_stash, eps = run_rollout(True)
         v_plain, ms_plain, _ = run_rollout(False)
         rollout = {"metric": "env_steps_per_sec", "value": v_stash, "unit": "env-steps/s",
+                   "parity": "unpinned (Connector.step semantics modelled on jumanji 0.2.2; the "
+                             "random policy is this project's, not jumanji's RandomAgent)",
                    "steps_per_launch": args.rollout_steps, "launches": launches,
                    "auto_reset": True, "kernel": "connector_rollout_kernel + stash_refill_kernel",
                    "launch_avg_ms": ms_stash, "episodes_per_launch": eps,
@@ -548,6 +781,8 @@ def main() -> None:
                        "max_walk_iters": metrics["max_iters"]},
             "roofline": roofline, "cpu_baseline": cpu, "env_step": env_step, "rollout": rollout,
         }
+        if copy_gbs is not None:
+            line["roofline"]["peak_measured_copy"] = copy_gbs
         if pipelined is not None:
             line["pipelined"] = pipelined
         print(json.dumps(line), flush=True)

@@ -346,7 +346,15 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
   }
 }
 
-__global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
+// One body, three kernels (reset / observe / step) so that every launch population has its own
+// name in a rocprofv3 kernel trace.
+enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
+
+template <int MODE>
+__device__ __forceinline__ void connector_body(const EnvArgs &a) {
+#if defined(RBG_PROBE_STEP_TIMES)  // developer probe (tools/probe_step.py --times)
+  const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
+#endif
   const int lane = threadIdx.x & (kWaveSize - 1);
   const SubWave<64> sw(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   const int N = a.N;
   AgentRegs ag = {0, 0, 0, 0, 0, 0};
 
-  if (a.mode == 0) {  // ---- Connector.reset ---------------------------------------------------
+  if constexpr (MODE == kModeReset) {  // ---- Connector.reset ----------------------------------
     Key2 kin;
     kin.a = a.keys[2 * (size_t)b];
     kin.b = a.keys[2 * (size_t)b + 1];
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   Key2 key;
   load_state(sw, board, g, N, b, a.in, ag, step_count, key);
 
-  if (a.mode == 1) {  // ---- observe an existing state (restart timestep) ----------------------
+  if constexpr (MODE == kModeObserve) {  // ---- observe an existing state (restart timestep) ---
     write_observation(sw, board, g, N, b, ag, step_count, a.ts,
                       lane < N ? action_mask_bits(board, g, ag, lane) : 1u);
     write_extras(sw, board, g, N, b, ag, a.ts);
@@ -413,6 +421,26 @@ __global__ __launch_bounds__(kBlock) void connector_kernel(EnvArgs a) {
   }
   store_state(sw, board, g, N, b, ag, step_count, key, a.out);
   write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
+#if defined(RBG_PROBE_STEP_TIMES)
+  // wave start / end (10 ns ticks) and where it ran, in place of three extras (probe builds only)
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores have left the wave
+  if (lane == 0) {
+    a.ts.num_connections[b] = (int32_t)probe_t0;
+    a.ts.total_path_length[b] = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();
+    a.ts.obs_step_count[b] = (int)(((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 16) |
+                                   (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu));
+  }
+#endif
+}
+
+__global__ __launch_bounds__(kBlock) void connector_reset_kernel(EnvArgs a) {
+  connector_body<kModeReset>(a);
+}
+__global__ __launch_bounds__(kBlock) void connector_observe_kernel(EnvArgs a) {
+  connector_body<kModeObserve>(a);
+}
+__global__ __launch_bounds__(kBlock) void connector_step_kernel(EnvArgs a) {
+  connector_body<kModeStep>(a);
 }
 
 // Producer of the stash: for every env whose entry is not the one its running episode will need
@@ -874,8 +902,16 @@ int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *tra
 }
 
 static int launch_env(EnvArgs &a, void *stream, const char *what) {
-  hipLaunchKernelGGL(connector_kernel, dim3((a.B + kWavesPerBlock - 1) / kWavesPerBlock),
-                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  const dim3 grid((a.B + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
+  const size_t lds = lds_bytes(a.g);
+  hipStream_t st = (hipStream_t)stream;
+  if (a.mode == kModeReset) {
+    hipLaunchKernelGGL(connector_reset_kernel, grid, block, lds, st, a);
+  } else if (a.mode == kModeObserve) {
+    hipLaunchKernelGGL(connector_observe_kernel, grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL(connector_step_kernel, grid, block, lds, st, a);
+  }
   return check_hip(hipGetLastError(), what);
 }
 

@@ -388,7 +388,16 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
 #else
   const int max_iters = g.n;
 #endif
+#if defined(RBG_WALK_PRIO_LOOP)
+  __builtin_amdgcn_s_setprio(RBG_WALK_PRIO_LOOP);
+#endif
   for (int t = 0; t < max_iters; ++t) {
+#if defined(RBG_WALK_PRIO_AT)
+    // A wave still walking after RBG_WALK_PRIO_AT iterations holds a long board: from here on
+    // it outranks the younger/older wave it shares the SIMD with in VALU arbitration (the launch
+    // lasts as long as its slowest wave).
+    if (t == RBG_WALK_PRIO_AT) __builtin_amdgcn_s_setprio(RBG_WALK_PRIO);
+#endif
     // randomness of the NEXT iteration is independent of the board: its LDS read goes first ...
     uint2 kk = make_uint2(0u, 0u);
     uint2 kk1 = make_uint2(0u, 0u);
@@ -468,6 +477,9 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
     wave_lds_fence();
     u = u_next;  // _step (:98) carried split(key)[1]: that is kcur's pipeline
   }
+#if defined(RBG_WALK_PRIO_LOOP) && defined(RBG_WALK_PRIO_RESET)
+  __builtin_amdgcn_s_setprio(0);
+#endif
   RBG_STAMP(w, 6);
   w.iters = sw.max_i32(last_live);  // while_loop trip count of this lane's board
 

@@ -739,6 +739,31 @@ def test_bench_under_torchrun_with_a_one_rank_rccl_group():
     assert line["config"]["global_batch"] == 4096
 
 
+def test_bench_gpus_2_launches_itself_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts torchrun as a
+    child and relays rank 0's line.  Two ranks share GPU 0 over gloo (--rehearse-single-gpu: RCCL
+    refuses two ranks on one device), so the numbers mean nothing; the launch path, the sharding
+    (2 x 4096 boards) and the max-over-ranks timing are what is exercised."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(
+        [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10",
+         "--warmup", "2", "--mode", "generator", "--cpu-sample", "0", "--rehearse-single-gpu"],
+        capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 10 and line["value"] > 0
+    assert line["config"]["global_batch"] == 8192 and line["scaling"] == "weak"
+
+
 @pytest.mark.parametrize("prefetch", [False, True])
 def test_donated_stepping_matches_oracle(rbg, oracle, prefetch):
     """Connector(donate=True): the State is advanced in place and the TimeStep alternates between

@@ -32,3 +32,70 @@ for B in (4096, 16384, 65536):
     us = e0.elapsed_time(e1) / reps * 1e3
     gb = B * env_step_bytes(m, N) / 1e9
     print(f"B={B:6d}  {us:8.1f} us/launch  {gb / (us * 1e-6) / 1e3:6.2f} TB/s algorithmic")
+
+
+def probe_times():
+    """Per-wave timeline of one pure step launch at B = 4096 (probe build -DRBG_PROBE_STEP_TIMES:
+    s_memrealtime at wave entry and after its last store, 10 ns ticks, one clock for the chip)."""
+    import ctypes as C
+    import subprocess
+
+    import numpy as np
+
+    from routing_board_generation_amd import _native as nat
+
+    so = os.path.join(ROOT, "gpurun_out", "librbg_probe_step_times.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                          ["-DRBG_PROBE_STEP_TIMES", "-o", so, nat.SRC_PATH])
+    lib = C.CDLL(so)
+    for B in (4096, 16384):
+        keys = rbg.split(rbg.PRNGKey(0), B)
+        st, ts = ops.connector_reset(keys, m, N)
+        act = torch.zeros((B, N), dtype=torch.int32, device="cuda")
+        so_ = ops.alloc_state(B, m, N, "cuda")
+        s_in, s_out = ops._state_struct(st, B, m, N), ops._state_struct(so_, B, m, N)
+        t_ = ops._timestep_struct(ts, B, m, N)
+        p = nat.EnvParams(1 << 30, -0.03, 0.1, 0)
+        for rep in range(4):
+            rc = lib.rbg_connector_step(B, m, N, C.byref(s_in), C.byref(s_out),
+                                        C.c_void_p(act.data_ptr()), C.byref(p), C.byref(t_),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+        t0 = ts["num_connections"].cpu().numpy().astype(np.uint32)
+        t1 = ts["total_path_length"].cpu().numpy().astype(np.uint32)
+        hw = ts["obs_step_count"].cpu().numpy()
+        base = t0.min()
+        start = (t0 - base).astype(np.int64) * 10  # ns
+        end = (t1 - base).astype(np.int64) * 10
+        dur = end - start
+        xcd, cu = hw >> 16, (hw >> 8) & 0xFF
+        print(f"B={B}: launch span (first wave start -> last wave end) {end.max() / 1e3:.2f} us; "
+              f"wave duration mean {dur.mean() / 1e3:.2f} p50 {np.median(dur) / 1e3:.2f} "
+              f"p95 {np.percentile(dur, 95) / 1e3:.2f} max {dur.max() / 1e3:.2f} us")
+        qs = [0, 10, 25, 50, 75, 90, 100]
+        print("  start time percentiles (us): " +
+              " ".join(f"p{q}={np.percentile(start, q) / 1e3:.2f}" for q in qs))
+        print("  end time percentiles (us):   " +
+              " ".join(f"p{q}={np.percentile(end, q) / 1e3:.2f}" for q in qs))
+        # concurrency: waves in flight over time
+        ev = np.concatenate([np.stack([start, np.ones_like(start)], 1),
+                             np.stack([end, -np.ones_like(end)], 1)])
+        ev = ev[np.argsort(ev[:, 0], kind="stable")]
+        inflight = np.cumsum(ev[:, 1])
+        grid = np.arange(0, end.max(), 500)
+        idx = np.searchsorted(ev[:, 0], grid, side="right") - 1
+        print("  waves in flight every 0.5 us: " + " ".join(str(int(inflight[i])) for i in idx))
+        per_xcd = [int((xcd == x).sum()) for x in range(8)]
+        print(f"  waves per XCD {per_xcd}; distinct (xcd, cu) pairs {len(set(zip(xcd, cu)))}")
+        # by block index: when do late blocks start?
+        blk = np.arange(B) // 4
+        for lo in range(0, B // 4, B // 32):
+            sel = (blk >= lo) & (blk < lo + B // 32)
+            print(f"  blocks {lo:5d}..: start {start[sel].mean() / 1e3:6.2f}  "
+                  f"dur {dur[sel].mean() / 1e3:5.2f}  end {end[sel].mean() / 1e3:6.2f} us")
+
+
+if __name__ == "__main__" and "--times" in sys.argv:
+    probe_times()

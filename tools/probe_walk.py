@@ -72,6 +72,12 @@ def main():
     ap.add_argument("--subsets", action="store_true",
                     help="time subsets / orderings of the C2 keys (longest pair alone, sorted by "
                          "walk length, ...): what bounds the launch")
+    ap.add_argument("--prio", type=str, default="",
+                    help="probe builds that raise the wave priority once the walk passes an "
+                         "iteration count: comma list of AT:PRIO pairs, e.g. 24:1,32:1,32:3")
+    ap.add_argument("--flags", type=str, default="",
+                    help="probe builds with extra hipcc flags: ';'-separated flag sets, e.g. "
+                         "'-falign-loops=64;-falign-loops=256'")
     ap.add_argument("--batches", type=str, default="64,256,1024,2048,4096,8192,16384,65536")
     args = ap.parse_args()
     print(f"# {args.m}x{args.m}/{args.n}: kernel time (us, p50) vs batch")
@@ -88,6 +94,33 @@ def main():
             us, mean_it, max_it = time_generate(B, args.m, args.n, lib=lib)
             print(f"cap={cap:4d} B={B:5d}  {us:9.1f} us  (iters mean {mean_it:.1f} max {max_it})")
     probe_stages(args)
+    for spec in [x for x in args.prio.split(",") if x]:
+        at, prio = (int(v) for v in spec.split(":"))
+        so = os.path.join(ROOT, "gpurun_out", f"librbg_probe_prio_{at}_{prio}.so")
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        if at == -1:    # whole loop at `prio`, never lowered
+            defs = [f"-DRBG_WALK_PRIO_LOOP={prio}"]
+        elif at == -2:  # whole loop at `prio`, back to 0 for the write-out
+            defs = [f"-DRBG_WALK_PRIO_LOOP={prio}", "-DRBG_WALK_PRIO_RESET"]
+        else:
+            defs = [f"-DRBG_WALK_PRIO_AT={at}", f"-DRBG_WALK_PRIO={prio}"]
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                              defs + ["-o", so, nat.SRC_PATH])
+        lib = C.CDLL(so)
+        for B in (4096, 16384):
+            runs = [time_generate(B, args.m, args.n, reps=300, lib=lib)[0] for _ in range(3)]
+            print(f"prio {prio} from iteration {at:3d}: B={B:5d}  "
+                  + "  ".join(f"{u:7.2f}" for u in runs) + " us", flush=True)
+    for i, fl in enumerate([x for x in args.flags.split(";") if x]):
+        so = os.path.join(ROOT, "gpurun_out", f"librbg_probe_flags_{i}.so")
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                              fl.split() + ["-o", so, nat.SRC_PATH])
+        lib = C.CDLL(so)
+        for B in (4096, 16384):
+            runs = [time_generate(B, args.m, args.n, reps=300, lib=lib)[0] for _ in range(3)]
+            print(f"flags {fl!r}: B={B:5d}  " + "  ".join(f"{u:7.2f}" for u in runs) + " us",
+                  flush=True)
     if args.placement:
         probe_placement(args)
     if args.times:

@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
-"""Copy the judged summaries of a rocprofv3 run from gpurun_out/ (scratch) into profiles/.
+"""Copy the judged summaries of rocprofv3 runs from gpurun_out/ (scratch) into profiles/.
 
-    python tools/summarize_profile.py r1b    # reads gpurun_out/prof_r1b_{trace,fetch,write}
+    python tools/summarize_profile.py r2 [suffix ...]
 
-Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, verbatim) and
-profiles/<tag>_hbm_traffic.md (per-kernel FETCH_SIZE / WRITE_SIZE from the two --pmc passes,
-with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md section HBM).
+For every suffix s (default: "", i.e. the plain bench.py run) it reads
+gpurun_out/prof_<tag><s>_{trace,fetch,write,issue} and writes
+  profiles/<tag><s>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+  profiles/<tag><s>_hbm_traffic.md/json  FETCH_SIZE / WRITE_SIZE per kernel (two --pmc passes)
+  profiles/<tag><s>_issue.md/json      SQ instruction / cycle counters (one more --pmc pass)
+Suffixes name the single-population runs of bench.py: "_step" (--mode step-replay), "_stream"
+(--mode stream).
+
+gfx950 corrections (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of the
+bytes of a WIDE coalesced streaming read (16 B per lane); it is doubled only for the kernels
+whose reads are such streams (WIDE_READS); other access widths are uncalibrated and shown raw.
+WRITE_SIZE is exact for 16-B-per-lane streaming stores.
 """
 import collections
 import csv
 import glob
+import json
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernels that read their state with global_load_dwordx4 streams (grids, 16 B per lane)
+WIDE_READS = ("connector_step_kernel", "connector_observe_kernel", "connector_rollout_kernel")
 
 
 def per_kernel(path, counter):
@@ -25,70 +38,73 @@ def per_kernel(path, counter):
     return agg
 
 
-def main():
-    tag = sys.argv[1]
-    out = os.path.join(ROOT, "profiles")
-    os.makedirs(out, exist_ok=True)
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
+def short(k):
+    return k.split("(anonymous namespace)::")[1].split("(")[0]
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def one(tag, out):
+    src = lambda kind, pat: glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{kind}", "*", pat))  # noqa
+    stats = src("trace", "*_kernel_stats.csv")
     if stats:
         shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
-    lines = [f"# HBM traffic per launch ({tag})", "",
-             "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, counter unit KiB.",
-             "gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of a wide "
-             "coalesced streaming read, so the read column is also shown doubled; WRITE_SIZE is "
-             "exact for 16-B-per-lane streaming stores.", "",
-             "| kernel | launches | FETCH_SIZE KiB (raw) | read MB (x2 corrected) | WRITE_SIZE KiB | write MB |",
-             "|---|---|---|---|---|---|"]
-    fetch = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_fetch", "*", "*_counter_collection.csv"))
-    write = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_write", "*", "*_counter_collection.csv"))
-    f = per_kernel(fetch[0], "FETCH_SIZE") if fetch else {}
-    w = per_kernel(write[0], "WRITE_SIZE") if write else {}
-    summary = {}
-    for k in sorted(set(f) | set(w)):
-        if "anonymous namespace" not in k:
-            continue
-        fv = sorted(f.get(k, [0.0]))
-        wv = sorted(w.get(k, [0.0]))
-        fm, wm = fv[len(fv) // 2], wv[len(wv) // 2]
-        name = k.split("(anonymous namespace)::")[1].split("(")[0]
-        lines.append(f"| {name} | {len(fv)} | {fm:.1f} | {2 * fm * 1024 / 1e6:.2f} | {wm:.1f} | "
-                     f"{wm * 1024 / 1e6:.2f} |")
-        summary[name] = {"fetch_kib_raw": fm, "write_kib": wm,
-                         "hbm_bytes_per_launch": int((2 * fm + wm) * 1024),
-                         "launch": "B=4096, 16x16 grid, 10 agents"}
-    lines.append("")
-    lines.append("Values are the median over the launches of one bench.py run (B = 4096 boards/envs "
-                 "of 16x16/10 per launch); connector_kernel mixes 1 reset + N step launches.")
-    open(os.path.join(out, f"{tag}_hbm_traffic.md"), "w").write("\n".join(lines) + "\n")
-    import json
-    json.dump({"tag": tag, "kernels": summary},
-              open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
-    print("\n".join(lines))
-    issue = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_issue", "*", "*_counter_collection.csv"))
+    fetch, write = src("fetch", "*_counter_collection.csv"), src("write", "*_counter_collection.csv")
+    if fetch or write:
+        f = per_kernel(fetch[0], "FETCH_SIZE") if fetch else {}
+        w = per_kernel(write[0], "WRITE_SIZE") if write else {}
+        lines = [f"# HBM traffic per launch ({tag})", "",
+                 "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, counter unit "
+                 "KiB, medians over the launches of one bench.py run.",
+                 "read MB = FETCH_SIZE x 2 for kernels whose reads are 16-B-per-lane streams "
+                 "(gfx950 tallies 128-B requests at 64 B), raw for the others (uncalibrated "
+                 "access width); WRITE_SIZE is exact for 16-B-per-lane streaming stores.", "",
+                 "| kernel | launches | FETCH_SIZE KiB (raw) | read MB | x2 applied | WRITE_SIZE KiB | write MB |",
+                 "|---|---|---|---|---|---|---|"]
+        summary = {}
+        for k in sorted(set(f) | set(w)):
+            if "anonymous namespace" not in k:
+                continue
+            fm, wm = median(f.get(k, [0.0])), median(w.get(k, [0.0]))
+            name = short(k)
+            wide = name.split("<")[0] in WIDE_READS
+            rd = (2 if wide else 1) * fm * 1024
+            lines.append(f"| {name} | {len(f.get(k, w.get(k)))} | {fm:.1f} | {rd / 1e6:.2f} | "
+                         f"{'yes' if wide else 'no'} | {wm:.1f} | {wm * 1024 / 1e6:.2f} |")
+            summary[name] = {"fetch_kib_raw": fm, "write_kib": wm, "fetch_x2": wide,
+                             "hbm_bytes_per_launch": int(rd + wm * 1024)}
+        open(os.path.join(out, f"{tag}_hbm_traffic.md"), "w").write("\n".join(lines) + "\n")
+        json.dump({"tag": tag, "kernels": summary},
+                  open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+        print("\n".join(lines))
+    issue = src("issue", "*_counter_collection.csv")
     if issue:
         write_issue(tag, issue[0], out)
 
 
 def write_issue(tag, path, out):
-    """SQ instruction / cycle counters per kernel (one more --pmc pass): how busy the vector
-    issue ports are.  SQ_WAVE_CYCLES, SQ_ACTIVE_INST_* and SQ_WAIT_* count quad-cycles
-    (MI355X_MICROARCH.md, constants table)."""
+    """SQ instruction / cycle counters per kernel: how busy the vector issue ports are.
+    SQ_WAVE_CYCLES, SQ_ACTIVE_INST_* and SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md)."""
     names = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES",
              "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY")
     per = {n: per_kernel(path, n) for n in names}
     lines = [f"# Issue counters per launch ({tag})", "",
              "rocprofv3 --pmc " + " ".join(names) + " (one pass; medians over the launches of one",
-             "bench.py run, B = 4096, 16x16/10).  Cycle counters are quad-cycles.", "",
+             "bench.py run).  Cycle counters are quad-cycles.", "",
              "| kernel | waves | VALU | SALU | LDS | instr / wave | wave quad-cycles | active any | "
              "waiting (s_waitcnt) | VALU quad-cycles / wave quad-cycles |",
              "|---|---|---|---|---|---|---|---|---|---|"]
+    summary = {}
     for k in sorted(per["SQ_WAVES"]):
         if "anonymous namespace" not in k:
             continue
-        med = {n: sorted(per[n].get(k, [0.0]))[len(per[n].get(k, [0.0])) // 2] for n in names}
+        med = {n: median(per[n].get(k, [0.0])) for n in names}
         if med["SQ_WAVES"] == 0:
             continue
-        name = k.split("(anonymous namespace)::")[1].split("(")[0]
+        name = short(k)
         total = med["SQ_INSTS_VALU"] + med["SQ_INSTS_SALU"] + med["SQ_INSTS_LDS"]
         wc = max(med["SQ_WAVE_CYCLES"], 1.0)
         lines.append(f"| {name} | {med['SQ_WAVES']:.0f} | {med['SQ_INSTS_VALU']:.0f} | "
@@ -96,9 +112,23 @@ def write_issue(tag, path, out):
                      f"{total / med['SQ_WAVES']:.0f} | {wc:.0f} | "
                      f"{med['SQ_ACTIVE_INST_ANY'] / wc:.2f} | {med['SQ_WAIT_ANY'] / wc:.2f} | "
                      f"{med['SQ_ACTIVE_INST_VALU'] / wc:.2f} |")
+        summary[name] = {"waves": med["SQ_WAVES"], "valu_insts_per_launch": med["SQ_INSTS_VALU"],
+                         "salu_insts_per_launch": med["SQ_INSTS_SALU"],
+                         "lds_insts_per_launch": med["SQ_INSTS_LDS"],
+                         "wave_quad_cycles": med["SQ_WAVE_CYCLES"]}
     lines.append("")
     open(os.path.join(out, f"{tag}_issue.md"), "w").write("\n".join(lines) + "\n")
+    json.dump({"tag": tag, "kernels": summary},
+              open(os.path.join(out, f"{tag}_issue.json"), "w"), indent=1)
     print("\n".join(lines))
+
+
+def main():
+    tag = sys.argv[1]
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    for suffix in (sys.argv[2:] or [""]):
+        one(tag + suffix, out)
 
 
 if __name__ == "__main__":
