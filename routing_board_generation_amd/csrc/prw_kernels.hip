@@ -309,6 +309,79 @@ __device__ __forceinline__ int stash_lookup(const StashPtrs &st, int B, int b, K
   return row;
 }
 
+// The same lookup with its loads issued early: lane s < depth fetches (tag, ready_at) of row
+// s * B + b when the wave starts, so that an env that ends its episode a microsecond later finds
+// the answer in registers instead of starting two dependent global loads on the launch's tail.
+struct StashProbe {
+  uint2 tag;
+  int ready_at;
+};
+__device__ __forceinline__ StashProbe stash_probe_issue(const StashPtrs &st, int B, int b,
+                                                        int lane) {
+  StashProbe p = {make_uint2(0u, 0u), 0x7FFFFFFF};
+  if (st.tag && lane < st.depth) {
+    const int r = lane * B + b;
+    p.tag = *reinterpret_cast<const uint2 *>(&st.tag[2 * (size_t)r]);
+    p.ready_at = st.ready_at[r];
+  }
+  return p;
+}
+__device__ __forceinline__ int stash_probe_row(const StashPtrs &st, const StashProbe &p, int B,
+                                               int b, int lane, Key2 key, int tick) {
+  const bool ok = st.tag && lane < st.depth && tick >= p.ready_at && p.tag.x == key.a &&
+                  p.tag.y == key.b;
+  const uint64_t m = __ballot(ok) & 3ull;  // depth <= 2; the later slot wins, as in stash_lookup
+  return m == 0ull ? -1 : (m & 2ull ? B + b : b);
+}
+
+// An episode that ends on the time limit is known to end as soon as step_count is loaded: its
+// wave fetches the stash row while it steps (registers only; one dwordx4 per lane covers grids
+// up to 16x16) and finds the next episode's State ready when it gets there.  Other terminations
+// (every agent connected or blocked) take the plain load_state path.
+struct RowPrefetch {
+  int row;  // -1: nothing prefetched
+  int4 grid;
+  int2 s, t, p;
+  uint2 key;
+};
+__device__ __forceinline__ RowPrefetch stash_row_issue(const StatePtrs &next, const Geo &g, int N,
+                                                       int row, int lane) {
+  RowPrefetch pf;
+  pf.row = row;
+  pf.grid = make_int4(0, 0, 0, 0);
+  pf.s = pf.t = pf.p = make_int2(0, 0);
+  pf.key = make_uint2(0u, 0u);
+  if (row >= 0) {
+    if (lane * 4 < g.n)
+      pf.grid = *reinterpret_cast<const int4 *>(&next.grid[(size_t)row * g.n + lane * 4]);
+    if (lane < N) {
+      const size_t o = ((size_t)row * N + lane) * 2;
+      pf.s = *reinterpret_cast<const int2 *>(&next.start[o]);
+      pf.t = *reinterpret_cast<const int2 *>(&next.target[o]);
+      pf.p = *reinterpret_cast<const int2 *>(&next.position[o]);
+    }
+    pf.key = *reinterpret_cast<const uint2 *>(&next.key[2 * (size_t)row]);
+  }
+  return pf;
+}
+__device__ __forceinline__ void stash_row_commit(const SubWave<64> &sw, uint32_t *board,
+                                                 const Geo &g, const RowPrefetch &pf,
+                                                 AgentRegs &ag, Key2 &key) {
+  const int lane = sw.l;
+  for (int w = lane; w < g.words; w += kWaveSize) board[w] = kWall;
+  wave_lds_fence();
+  if (lane * 4 < g.n) {
+    const int r = div_m(g, lane * 4);
+    *reinterpret_cast<uint4 *>(&board[pad_index(g, r, lane * 4 - r * g.m)]) =
+        make_uint4((uint32_t)pf.grid.x, (uint32_t)pf.grid.y, (uint32_t)pf.grid.z,
+                   (uint32_t)pf.grid.w);
+  }
+  wave_lds_fence();
+  ag.r0 = pf.s.x; ag.c0 = pf.s.y; ag.tr = pf.t.x; ag.tc = pf.t.y; ag.r = pf.p.x; ag.c = pf.p.y;
+  key.a = pf.key.x;
+  key.b = pf.key.y;
+}
+
 // After a (re)start with State.key `key`: ask the next refill for what comes after it
 // (include/rbg_prw.h::rbg_stash).  depth 1: the env's one row is requested for `key`.  depth 2:
 // one row is reserved for `key` unless one already is, and the other -- just consumed, or never
@@ -346,6 +419,11 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
   }
 }
 
+#ifndef RBG_ENV_WPB
+#define RBG_ENV_WPB 4
+#endif
+constexpr int kEnvWavesPerBlock = RBG_ENV_WPB;  // waves (envs) per workgroup of the env kernels
+
 // One body, three kernels (reset / observe / step) so that every launch population has its own
 // name in a rocprofv3 kernel trace.
 enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
@@ -358,7 +436,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
   const SubWave<64> sw(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x * kWavesPerBlock + wib;
+  const int b = blockIdx.x * kEnvWavesPerBlock + wib;
   if (b >= a.B) return;
   uint32_t *board = g_lds + wib * slab_words<64>(a.g);
   uint32_t *W = board + board_words(a.g);
@@ -394,20 +472,48 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 
   // ---- Connector.step --------------------------------------------------------------------------
   const int act = lane < N ? a.action[(size_t)b * N + lane] : 0;
+  const StashProbe probe = stash_probe_issue(a.stash, a.B, b, lane);  // in flight during the step
+  RowPrefetch pf;
+  pf.row = -1;
+  if (a.p.auto_reset && a.stash.tag && step_count + 1 >= a.p.time_limit && (g.m & 3) == 0 &&
+      g.n <= 4 * kWaveSize)  // wave-uniform
+    pf = stash_row_issue(a.stash.next, g, N,
+                         stash_probe_row(a.stash, probe, a.B, b, lane, key, a.tick), lane);
+#if defined(RBG_PROBE_SKIP_STEP)  // developer probe: load -> store only (wrong results)
+  StepResult res;
+  res.was_connected = res.connected = res.done = res.last = false;
+  res.bits = 1u + (uint32_t)act;
+#else
   const StepResult res = env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit);
-  write_step_outcome(sw, res, a.p, N, b, a.ts);
-  write_extras(sw, board, g, N, b, ag, a.ts);
-  uint32_t bits = res.bits;  // action mask of the state that is observed next
+#endif
 
-  if (res.last && a.p.auto_reset) {
+  if (!(res.last && a.p.auto_reset)) {
+    // The common case.  Every wave of a launch reaches this point at about the same time, and
+    // until the first of them stores, the HBM write path -- what bounds the launch -- is idle:
+    // the 10 KB observation goes out first, then the state, and the small outputs (reward,
+    // extras: ballots and a pass over the board) are computed while those stores drain.
+    write_observation(sw, board, g, N, b, ag, step_count, a.ts, res.bits);
+    store_state(sw, board, g, N, b, ag, step_count, key, a.out);
+    write_step_outcome(sw, res, a.p, N, b, a.ts);
+    write_extras(sw, board, g, N, b, ag, a.ts);
+  } else {
+    // the few waves that restart an episode have the longest path through this kernel and
+    // every wave of the launch started together: let them go first wherever they compete
+    __builtin_amdgcn_s_setprio(3);
+    write_step_outcome(sw, res, a.p, N, b, a.ts);
+    write_extras(sw, board, g, N, b, ag, a.ts);  // of the terminal state
     // VmapAutoResetWrapper._auto_reset: key, _ = split(state.key); state, ts = reset(key);
     // only the observation of the terminal timestep is replaced.
     // With a stash the new episode's State was generated ahead of time (stash_refill_kernel)
     // and is only copied here; the entry is valid iff it was generated for exactly this
     // episode's key and the refill that wrote it is known to have completed (ready_at: ordered
     // by the host through the stream, never through in-kernel flags).
-    const int row = stash_lookup(a.stash, a.B, b, key, a.tick);
-    if (row >= 0) {
+    const int row = pf.row >= 0 ? pf.row
+                                : stash_probe_row(a.stash, probe, a.B, b, lane, key, a.tick);
+    if (pf.row >= 0) {
+      stash_row_commit(sw, board, g, pf, ag, key);
+      if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
+    } else if (row >= 0) {
       load_state(sw, board, g, N, row, a.stash.next, ag, step_count, key);
       if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
     } else {
@@ -417,10 +523,10 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
     }
     step_count = 0;
     request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
-    bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
+    const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
+    store_state(sw, board, g, N, b, ag, step_count, key, a.out);
+    write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
   }
-  store_state(sw, board, g, N, b, ag, step_count, key, a.out);
-  write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
 #if defined(RBG_PROBE_STEP_TIMES)
   // wave start / end (10 ns ticks) and where it ran, in place of three extras (probe builds only)
   __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores have left the wave
@@ -433,13 +539,13 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 #endif
 }
 
-__global__ __launch_bounds__(kBlock) void connector_reset_kernel(EnvArgs a) {
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_kernel(EnvArgs a) {
   connector_body<kModeReset>(a);
 }
-__global__ __launch_bounds__(kBlock) void connector_observe_kernel(EnvArgs a) {
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_observe_kernel(EnvArgs a) {
   connector_body<kModeObserve>(a);
 }
-__global__ __launch_bounds__(kBlock) void connector_step_kernel(EnvArgs a) {
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_kernel(EnvArgs a) {
   connector_body<kModeStep>(a);
 }
 
@@ -902,8 +1008,9 @@ int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *tra
 }
 
 static int launch_env(EnvArgs &a, void *stream, const char *what) {
-  const dim3 grid((a.B + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-  const size_t lds = lds_bytes(a.g);
+  const dim3 grid((a.B + kEnvWavesPerBlock - 1) / kEnvWavesPerBlock),
+      block(kWaveSize * kEnvWavesPerBlock);
+  const size_t lds = lds_bytes(a.g) / kWavesPerBlock * kEnvWavesPerBlock;
   hipStream_t st = (hipStream_t)stream;
   if (a.mode == kModeReset) {
     hipLaunchKernelGGL(connector_reset_kernel, grid, block, lds, st, a);

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from bench import env_step_bytes  # noqa: E402
 
 m, N = 16, 10
-for B in (4096, 16384, 65536):
+for B in ((4096, 16384, 65536) if len(sys.argv) == 1 else ()):
     keys = rbg.split(rbg.PRNGKey(0), B)
     st, ts = ops.connector_reset(keys, m, N)
     act = torch.zeros((B, N), dtype=torch.int32, device="cuda")  # NOOP: nothing ever terminates
@@ -99,3 +99,70 @@ def probe_times():
 
 if __name__ == "__main__" and "--times" in sys.argv:
     probe_times()
+
+
+def probe_gaps():
+    """Launch-interval floor of this stack: a trivial kernel back to back, the step kernel back to
+    back through direct ctypes calls, and the same step launches replayed from a hipGraph."""
+    import ctypes as C
+
+    from routing_board_generation_amd import _native as nat
+
+    lib = nat.lib()
+    flags = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--flags=")]
+    if flags:
+        import subprocess
+        so = os.path.join(ROOT, "gpurun_out", "librbg_probe_gaps.so")
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                              flags[0].split() + ["-o", so, nat.SRC_PATH])
+        lib = C.CDLL(so)
+        print(f"probe build with {flags[0]}")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.empty((4, 2), dtype=torch.uint32, device="cuda")
+
+    def span(fn, reps):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    print(f"trivial kernel (rbg_split, 1 block): {span(lambda: lib.rbg_split(1, 2, 4, C.c_void_p(out.data_ptr()), stream), 500):.2f} us per launch")
+    for B in (2048, 4096, 4096, 8192):
+        keys = rbg.split(rbg.PRNGKey(0), B)
+        st, ts = ops.connector_reset(keys, m, N)
+        act = torch.zeros((B, N), dtype=torch.int32, device="cuda")
+        so_ = ops.alloc_state(B, m, N, "cuda")
+        s_in, s_out = ops._state_struct(st, B, m, N), ops._state_struct(so_, B, m, N)
+        t_ = ops._timestep_struct(ts, B, m, N)
+        p = nat.EnvParams(1 << 30, -0.03, 0.1, 0)
+
+        def launch():
+            rc = lib.rbg_connector_step(B, m, N, C.byref(s_in), C.byref(s_out),
+                                        C.c_void_p(act.data_ptr()), C.byref(p), C.byref(t_),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+
+        direct = span(launch, 300)
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            launch()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(20):
+                    launch()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = span(g.replay, 20) / 20
+        print(f"B={B:6d}: direct {direct:7.2f} us/launch   hipGraph of 20 {graph:7.2f} us/launch",
+              flush=True)
+
+
+if __name__ == "__main__" and "--gaps" in sys.argv:
+    probe_gaps()
