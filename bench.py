@@ -130,26 +130,66 @@ def issue_roofline(kernel: str, boards: int, kernel_avg_ms: float):
                     "instruction; the launch also waits for its longest board (DESIGN.md 4.1)"}
 
 
-def copy_peak_gbs(dev) -> float:
-    """Measured HBM copy rate of this GPU (quoted beside the 8 TB/s spec figure):
-    a 1 GiB device-to-device copy kernel (torch's elementwise copy), read + written bytes."""
+def build_microbench() -> str:
+    """tools/microbench/hbm_peak.hip -> libhbm_peak.so (built by __graft_entry__.build(); rebuilt
+    here if missing -- hipcc is on the GPU box too)."""
+    import subprocess
+
+    src = os.path.join(ROOT, "tools", "microbench", "hbm_peak.hip")
+    so = os.path.join(ROOT, "tools", "microbench", "libhbm_peak.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"),
+                               "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, src])
+    return so
+
+
+def hbm_peaks(dev) -> dict:
+    """Measured HBM rates of this GPU (quoted beside the 8 TB/s spec figure): a
+    16-B-per-lane copy (read + written bytes) and a write-only fill, plain and non-temporal,
+    1 GiB buffers (far beyond the 256 MiB Infinity Cache); best of the grid sizes tried."""
+    import ctypes as C
+
     import torch
 
-    n = 1 << 28  # float32 elements = 1 GiB per buffer, far beyond the 256 MiB Infinity Cache
-    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    lib = C.CDLL(build_microbench())
+    lib.hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    lib.hbm_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    nbytes = 1 << 30
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
-    for _ in range(2):
-        dst.copy_(src)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    e0.record()
-    for _ in range(10):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / 10
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def rate(fn, moved):
+        best = 0.0
+        for blocks in (1024, 2048, 4096, 16384):
+            for _ in range(2):
+                fn(blocks)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(10):
+                fn(blocks)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            best = max(best, moved / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9)
+        return best
+
+    out = {}
+    for nt in (0, 1):
+        tag = "_nontemporal" if nt else ""
+        out["copy" + tag] = rate(lambda b: lib.hbm_copy(dst.data_ptr(), src.data_ptr(), nbytes,
+                                                        nt, b, stream), 2 * nbytes)
+        out["fill" + tag] = rate(lambda b: lib.hbm_fill(dst.data_ptr(), nbytes, nt, b, stream),
+                                 nbytes)
     del src, dst
-    return 2 * n * 4 / (ms * 1e-3) / 1e9
+    out["unit"] = "GB/s"
+    out["note"] = ("tools/microbench/hbm_peak.hip: float4 copy (bytes read + written) and "
+                   "write-only fill over 1 GiB, each wave on contiguous 16 KiB chunks")
+    return out
+
+
+def copy_peak_gbs(dev) -> float:
+    return hbm_peaks(dev)["copy"]
 
 
 def free_port() -> int:
@@ -364,11 +404,13 @@ def pure_stream(rbg, ops, torch, dev, m, N, sb, Bs, copy_gbs=None):
     torch.cuda.synchronize(dev)
     p_ms = pe0.elapsed_time(pe1) / 20
     p_ach = Bs * sb / (p_ms * 1e-3) / 1e9
-    if copy_gbs is None:
-        copy_gbs = copy_peak_gbs(dev)
+    peaks = hbm_peaks(dev) if copy_gbs is None else None
+    if peaks:
+        copy_gbs = max(peaks["copy"], peaks["copy_nontemporal"])
     return {"batch": Bs, "launches": 23, "kernel_avg_ms": p_ms, "achieved": p_ach, "unit": "GB/s",
             "peak": HBM_PEAK_GBS, "frac": p_ach / HBM_PEAK_GBS,
             "peak_measured_copy": copy_gbs, "frac_of_measured_copy": p_ach / copy_gbs,
+            **({"peak_measured": peaks} if peaks else {}),
             "algorithmic_bytes_per_launch": Bs * sb,
             "note": "connector_step_kernel, NOOP actions (no terminations), working set "
                     f"{Bs * sb / 1e6:.0f} MB > 256 MiB Infinity Cache; 92 % of its bytes are "
@@ -547,7 +589,8 @@ def main() -> None:
     #   fused_policy prefetch + policy and step in one launch (rbg_connector_rollout, 1 step)
     #   no_auto_reset  auto-reset off: finished envs stay terminal, no walk ever runs
     env_step = None
-    copy_gbs = copy_peak_gbs(dev) if (rank == 0 and args.mode != "generator") else None
+    peaks = hbm_peaks(dev) if (rank == 0 and args.mode != "generator") else None
+    copy_gbs = max(peaks["copy"], peaks["copy_nontemporal"]) if peaks else None
     if args.env_steps > 0:
         sb = env_step_bytes(m, N)
 
@@ -781,8 +824,8 @@ def main() -> None:
                        "max_walk_iters": metrics["max_iters"]},
             "roofline": roofline, "cpu_baseline": cpu, "env_step": env_step, "rollout": rollout,
         }
-        if copy_gbs is not None:
-            line["roofline"]["peak_measured_copy"] = copy_gbs
+        if peaks is not None:
+            line["roofline"]["peak_measured"] = peaks
         if pipelined is not None:
             line["pipelined"] = pipelined
         print(json.dumps(line), flush=True)

@@ -614,8 +614,27 @@ struct RolloutArgs {
 // lanes of the wave wait -- every cross-lane operation of the env and walk code stays inside a
 // sub-wave, so that divergence is legal.
 // (LPB 64: 4 waves per SIMD = one launch of 4096 envs resident at once, VGPR budget 128.)
+#ifndef RBG_ROLLOUT64_WAVES
+#define RBG_ROLLOUT64_WAVES 4
+#endif
+// Per-env values are uniform inside the sub-wave; for a full-wave env that is wave-uniform, and
+// saying so moves them to SGPRs (the 128-VGPR budget of 4 waves per SIMD is tight: without this
+// connector_rollout_kernel<64> spilled 8 dwords).
 template <int LPB>
-__global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_rollout_kernel(
+__device__ __forceinline__ int uni(int v) {
+  if constexpr (LPB == kWaveSize) return __builtin_amdgcn_readfirstlane(v);
+  return v;
+}
+template <int LPB>
+__device__ __forceinline__ Key2 uni(Key2 k) {
+  if constexpr (LPB == kWaveSize) {
+    k.a = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.a);
+    k.b = (uint32_t)__builtin_amdgcn_readfirstlane((int)k.b);
+  }
+  return k;
+}
+template <int LPB>
+__global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? RBG_ROLLOUT64_WAVES : 2)) void connector_rollout_kernel(
     RolloutArgs a) {
   constexpr int kSubs = SubWave<LPB>::kSubs;
   const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
@@ -634,6 +653,9 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_
   load_state(sw, board, g, N, b, a.in, ag, step_count, key);
   pk.a = a.policy_keys[2 * (size_t)b];
   pk.b = a.policy_keys[2 * (size_t)b + 1];
+  step_count = uni<LPB>(step_count);
+  key = uni<LPB>(key);
+  pk = uni<LPB>(pk);
 
   int episodes = 0, conn_made = 0, pen_steps = 0, fin_conn = 0, fin_plen = 0;
   uint32_t bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
@@ -651,17 +673,18 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_
     const StepResult res =
         env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit, pf);
     bits = res.bits;
-    conn_made += __popcll(sw.ballot(!res.was_connected && res.connected));
-    pen_steps += __popcll(sw.ballot(is_agent && !res.was_connected));
+    step_count = uni<LPB>(step_count);
+    conn_made = uni<LPB>(conn_made + __popcll(sw.ballot(!res.was_connected && res.connected)));
+    pen_steps = uni<LPB>(pen_steps + __popcll(sw.ballot(is_agent && !res.was_connected)));
     const bool final_step = s == a.n_steps - 1;
     if (final_step) {
       write_step_outcome(sw, res, a.p, N, b, a.ts);
       write_extras(sw, board, g, N, b, ag, a.ts);
     }
     if (res.last) {  // per env
-      episodes += 1;
-      fin_conn += __popcll(sw.ballot(res.connected));
-      if (a.stats.final_path_length) fin_plen += count_path_cells(sw, board, g);
+      episodes = uni<LPB>(episodes + 1);
+      fin_conn = uni<LPB>(fin_conn + __popcll(sw.ballot(res.connected)));
+      if (a.stats.final_path_length) fin_plen = uni<LPB>(fin_plen + count_path_cells(sw, board, g));
       if (a.p.auto_reset) {
         // (rows do not change during a launch: a second reset finds its own row or none)
         const int row = stash_lookup(a.stash, a.B, b, key, a.tick);
@@ -674,6 +697,7 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? 4 : 2)) void connector_
           key = regenerate(sw, board, W, g, N, rk, ag);
         }
         step_count = 0;
+        key = uni<LPB>(key);
         request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
         bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
       }

@@ -43,7 +43,10 @@ __device__ __forceinline__ void shuffle_prefix(const SubWave<LPB> &sw, uint32_t 
     for (int k = 0; k < kKeyRounds; ++k) {
       klo[k] = khi[k] = 0u;
       if ((uint32_t)(k * LPB) < half) {
-        const uint32_t j = (uint32_t)(l + k * LPB);
+        uint32_t j = (uint32_t)(l + k * LPB);
+        // computed here, not hoisted above the calls: their operands would otherwise all be live
+        // across every call (the only spills of connector_rollout_kernel<64> were these)
+        asm volatile("" : "+v"(j));
         const uint2 y = threefry_call(sub.a, sub.b, j < half ? j : 0u, half + j < n ? half + j : 0u);
         klo[k] = y.x;
         khi[k] = y.y;

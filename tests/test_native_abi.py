@@ -78,3 +78,25 @@ def test_cpu_tensors_are_rejected_loudly():
     keys = torch.zeros((4, 2), dtype=torch.uint32)
     with pytest.raises(ValueError, match="no CPU path"):
         ops.prw_generate(keys, 16, 10, split_first=True)
+
+
+def test_no_kernel_spills_to_scratch(native, tmp_path):
+    """Every kernel of the library keeps its state in registers: the gfx950 assembly (hipcc -S,
+    device side only; no GPU needed) declares no private segment and no spilled VGPRs."""
+    import re
+    import subprocess
+
+    asm = tmp_path / "kernels.s"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = [f for f in native.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([hipcc] + flags + ["--cuda-device-only", "-S", "-o", str(asm),
+                                             native.SRC_PATH], stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n){0,12}?\s+\.private_segment_fixed_size:\s+(\d+)",
+                         text)
+    assert len(kernels) >= 20, f"only {len(kernels)} kernel descriptors found"
+    bad = [(n, s) for n, s in kernels if int(s) != 0]
+    assert not bad, f"kernels with scratch: {bad}"
+    spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)
+    assert spills and all(int(x) == 0 for x in spills), spills
+    assert "scratch_store" not in text and "scratch_load" not in text

@@ -48,7 +48,10 @@ def median(v):
 
 
 def one(tag, out):
-    src = lambda kind, pat: glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{kind}", "*", pat))  # noqa
+    def src(kind, pat):  # rocprofv3 writes into <dir>/ or <dir>/<host>/ depending on its version
+        base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{kind}")
+        return glob.glob(os.path.join(base, pat)) + glob.glob(os.path.join(base, "*", pat))
+
     stats = src("trace", "*_kernel_stats.csv")
     if stats:
         shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
