@@ -701,8 +701,8 @@ def main() -> None:
             return
         if args.mode == "stream":
             print(json.dumps({"mode": "stream", "kernel": "connector_step_kernel",
-                              **pure_stream(rbg, ops, torch, dev, m, N, sb, args.stream_batch)}),
-                  flush=True)
+                              **pure_stream(rbg, ops, torch, dev, m, N, sb, args.stream_batch,
+                                            copy_gbs), "peak_measured": peaks}), flush=True)
             return
         v_pref, k_pref = run_loop(16, False)
         k_step, k_span = step_kernel_ms(16)
