@@ -72,34 +72,55 @@ __host__ __device__ inline int se_extra_words(int words_padded, int n) {
 //   4,5  blocks (0,2),(1,3) of split(C_{s-1})            -> its second child D_{s-1} (y1)
 //   6    random_bits(C_{s-1}, ()) -> uniform of cell s-1  (use_random byte, kRnd only)
 //   8    random_bits(D_{s-2}, ()) -> direction number of chain position s-2 (idx byte)
-// Operands move by DPP (gfx9 dpp_ctrl encodings): row_shr:4 hands the y1 pair of a quad to the
-// next quad, quad_perm broadcasts lane 0 / lane 1 of the quad, and a bank-masked second move
-// gives quad 0 its y0 pair -- five moves, no selects, no LDS on the chain.
-// Every lane stores one byte per link through its own running pointer (increment 1 for the lane
-// whose byte is wanted, 0 for the others, which keep hitting their private dump byte): no
+// Operands move by DPP (gfx9 dpp_ctrl encodings): quad_perm broadcasts lane 0 / lane 1 of the
+// quad (the chain's y0 pair, one move deep), row_shr:4 hands the y1 pair of a quad to the next
+// quad, and a bank-masked quad_perm leaves quad 0 as it is -- five moves, no selects, no LDS on
+// the chain.
+// Every lane stores one byte per link through its own running pointer (se_chain_links): no
 // exec-mask branches in the loop.
 // ---------------------------------------------------------------------------------------------
+template <bool kRnd>
+__device__ __forceinline__ void se_chain_link(Key2 &ck, uint32_t cx0, uint32_t cx1,
+                                              uint8_t *idx_ptr, uint8_t *rnd_ptr, int ofs,
+                                              float randomness) {
+  uint32_t y0, y1;
+  // (a formulation with 36 dependent levels instead of 45 -- rotations distributed over the
+  // xors, v_xad_u32 + v_bitop3_b32, 10 more instructions -- was bit-exact and SLOWER, 75 vs 67 us
+  // per 16x16 sweep: a lone wave pays ~7 cycles per instruction of this loop whatever their
+  // dependencies, so the instruction count is what counts)
+  threefry(ck.a, ck.b, cx0, cx1, y0, y1);
+  // quad 0 (the chain) takes its y0 pair; the other quads get the y1 pair of the quad before
+  const int a0 = __builtin_amdgcn_update_dpp(0, (int)y0, 0x00, 0xF, 0xF, true);  // quad_perm:[0,0,0,0]
+  const int b0 = __builtin_amdgcn_update_dpp(0, (int)y0, 0x55, 0xF, 0xF, true);  // quad_perm:[1,1,1,1]
+  const int sh = __builtin_amdgcn_update_dpp(0, (int)y1, 0x114, 0xF, 0xF, true);  // row_shr:4
+  ck.a = (uint32_t)__builtin_amdgcn_update_dpp(a0, sh, 0x00, 0xF, 0xE, false);  // lanes 4..15
+  ck.b = (uint32_t)__builtin_amdgcn_update_dpp(b0, sh, 0x55, 0xF, 0xE, false);
+  idx_ptr[ofs] = (uint8_t)y0;  // low two bits = the direction number (masked by the reader)
+  if (kRnd) rnd_ptr[ofs] = (uint8_t)(randomness > bits_to_uniform(y0));
+}
+
+// `count` links.  Every lane stores one byte per link at its running pointer + 0..3 and then
+// moves the pointer on by 4 * inc: inc is 1 for the lane whose bytes are wanted and 0 for the
+// others, whose four stores keep hitting the four bytes of their private dump word.
 template <bool kRnd>
 __device__ __forceinline__ void se_chain_links(Key2 &ck, uint32_t cx0, uint32_t cx1, int count,
                                                uint8_t *&idx_ptr, int idx_inc, uint8_t *&rnd_ptr,
                                                int rnd_inc, float randomness) {
+  int s = 0;
 #pragma unroll 1
-  for (int s = 0; s < count; ++s) {
-    uint32_t y0, y1;
-    threefry(ck.a, ck.b, cx0, cx1, y0, y1);
-    const int sh = __builtin_amdgcn_update_dpp(0, (int)y1, 0x114, 0xF, 0xF, true);  // row_shr:4
-    int a = __builtin_amdgcn_update_dpp(0, sh, 0x00, 0xF, 0xF, true);   // quad_perm:[0,0,0,0]
-    int b = __builtin_amdgcn_update_dpp(0, sh, 0x55, 0xF, 0xF, true);   // quad_perm:[1,1,1,1]
-    a = __builtin_amdgcn_update_dpp(a, (int)y0, 0x00, 0xF, 0x1, false);  // lanes 0..3 of the row
-    b = __builtin_amdgcn_update_dpp(b, (int)y0, 0x55, 0xF, 0x1, false);
-    ck.a = (uint32_t)a;
-    ck.b = (uint32_t)b;
-    *idx_ptr = (uint8_t)y0;  // low two bits = the direction number (masked by the reader)
+  for (; s + 4 <= count; s += 4) {
+    se_chain_link<kRnd>(ck, cx0, cx1, idx_ptr, rnd_ptr, 0, randomness);  // immediate ds offsets
+    se_chain_link<kRnd>(ck, cx0, cx1, idx_ptr, rnd_ptr, 1, randomness);
+    se_chain_link<kRnd>(ck, cx0, cx1, idx_ptr, rnd_ptr, 2, randomness);
+    se_chain_link<kRnd>(ck, cx0, cx1, idx_ptr, rnd_ptr, 3, randomness);
+    idx_ptr += 4 * idx_inc;
+    rnd_ptr += 4 * rnd_inc;
+  }
+#pragma unroll 1
+  for (; s < count; ++s) {
+    se_chain_link<kRnd>(ck, cx0, cx1, idx_ptr, rnd_ptr, 0, randomness);
     idx_ptr += idx_inc;
-    if (kRnd) {
-      *rnd_ptr = (uint8_t)(randomness > bits_to_uniform(y0));
-      rnd_ptr += rnd_inc;
-    }
+    rnd_ptr += rnd_inc;
   }
 }
 

@@ -24,6 +24,41 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+import ctypes as C  # noqa: E402
+import subprocess  # noqa: E402
+
+from routing_board_generation_amd import _native as nat  # noqa: E402
+
+# --flags='-DX;-DY': also time probe builds (C5 shape only), interleaved with the library as built
+variants = [("as built", nat.lib())]
+for i, fl in enumerate([x for a in sys.argv if a.startswith("--flags=") for x in a[8:].split(";") if x]):
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                      f"librbg_probe_se_{i}.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                          fl.split() + ["-o", so, nat.SRC_PATH])
+    lib = C.CDLL(so)
+    for name, (restype, argtypes) in nat.SIGNATURES.items():
+        getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+    variants.append((fl, lib))
+if len(variants) > 1:
+    m, N, B = 16, 10, 4096
+    keys = rbg.split(rbg.PRNGKey(0), B)
+    out = ops.seed_extension_generate(keys, m, N, split_first=True)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        for label, lib in variants:
+            def launch():
+                rc = lib.rbg_seed_extension_generate(
+                    keys.data_ptr(), B, m, N, 1, 0.0, 1, 1, 2 ** 31 - 1, None,
+                    out["train_grid"].data_ptr(), out["start"].data_ptr(),
+                    out["target"].data_ptr(), out["position"].data_ptr(),
+                    out["step_count"].data_ptr(), out["key_out"].data_ptr(),
+                    out["sweeps"].data_ptr(), stream)
+                assert rc == 0, rc
+            print(f"{label:28s} {timed(launch, 5):9.1f} us per launch (C5: 16x16/10, B=4096)", flush=True)
+    sys.exit(0)
+
 rows = []
 for (m, N, B) in ((16, 10, 256), (16, 10, 1024), (16, 10, 4096), (16, 10, 16384), (16, 10, 65536),
                   (10, 5, 100), (10, 5, 4096), (32, 20, 4096)):
