@@ -246,11 +246,35 @@ class Connector:
         return _make_timestep(ops.connector_observe(_state_bufs(state, batched)), batched)
 
     def _get_action_mask(self, agents: Agent, grid: torch.Tensor) -> torch.Tensor:
-        """(N, 5) bool for all agents at once (the reference vmaps this over agents:
-        demos/board_generator_demo.py:85-87)."""
+        """[3P] Connector._get_action_mask(agent, grid).
+        * ONE agent (`agent.id` without an agent axis, as inside the reference's
+          `jax.vmap(env._get_action_mask, (0, None))(state.agents, state.grid)`,
+          demos/board_generator_demo.py:85-87): (5,) bool, or (B, 5) for a batch of grids with one
+          agent each;
+        * all agents at once (`agents.id` of shape (N,) / (B, N)): (N, 5) / (B, N, 5) -- what that
+          vmap returns, in one launch."""
         batched = grid.dim() == 3
         B = grid.shape[0] if batched else 1
         dev = grid.device
+        if agents.id.dim() == grid.dim() - 2:  # a single agent per grid
+            N = self.num_agents
+            ids = agents.id.reshape(B).long()
+            if bool(((ids < 0) | (ids >= N)).any()):
+                raise ValueError("agent.id outside [0, num_agents)")
+            rows = torch.arange(B, device=dev)
+
+            def slot(x, fill):  # (B, 2) -> (B, N, 2) with the agent in its own slot
+                full = torch.full((B, N, 2), fill, dtype=torch.int32, device=dev)
+                full[rows, ids] = x.reshape(B, 2).to(torch.int32)
+                return full
+
+            # the other slots sit on their own target off the board's reach: they are never read
+            every = Agent(id=torch.arange(N, dtype=torch.int32, device=dev).expand(B, N),
+                          start=slot(agents.start, 0), target=slot(agents.target, 0),
+                          position=slot(agents.position, 0))
+            g3 = grid if batched else grid[None]
+            mask = self._get_action_mask(every, g3)[rows, ids]
+            return mask if batched else mask[0]
         state = State(grid=grid, step_count=torch.zeros((B,) if batched else (), dtype=torch.int32, device=dev),
                       agents=agents,
                       key=torch.zeros((B, 2) if batched else (2,), dtype=torch.uint32, device=dev))

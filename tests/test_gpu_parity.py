@@ -345,6 +345,20 @@ def test_private_env_methods_used_by_the_reference(rbg, oracle):
     assert (to_np(obs) == ets["obs_grid"][0]).all()
     assert int(extras["num_connections"]) == int(ets["num_connections"][0])
     assert int(extras["total_path_length"]) == 0
+    # the reference's own call shape: one agent at a time (vmap over agents, :85-87)
+    for i in range(5):
+        one = rbg.Agent(id=state.agents.id[i], start=state.agents.start[i],
+                        target=state.agents.target[i], position=state.agents.position[i])
+        m1 = env._get_action_mask(one, state.grid)
+        assert m1.shape == (5,) and (to_np(m1).astype(np.uint8) == ets["action_mask"][0, i]).all()
+    # ... and a batch of grids with one agent each
+    bstate = rbg.UniformRandomGenerator(10, 5)(_keys(rbg, 3, 7))
+    est7, _, _ = oracle.generate_batch(to_np(_keys(rbg, 3, 7)), 10, 5, generator="uniform")
+    ets7 = oracle.connector_observe_batch(est7)
+    one = rbg.Agent(id=bstate.agents.id[:, 2], start=bstate.agents.start[:, 2],
+                    target=bstate.agents.target[:, 2], position=bstate.agents.position[:, 2])
+    mb = env._get_action_mask(one, bstate.grid)
+    assert mb.shape == (7, 5) and (to_np(mb).astype(np.uint8) == ets7["action_mask"][:, 2]).all()
 
 
 def test_uniform_generator_env_with_generic_auto_reset(rbg, oracle):
