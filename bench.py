@@ -716,11 +716,16 @@ def main() -> None:
                        "State/TimeStep pytrees; functional = fresh output tensors every step, "
                        "donate = State advanced in place + two alternating TimeStep buffers"}
         ach = B * sb / (k_step * 1e-3) / 1e9
-        env_step = {"metric": "env_steps_per_sec", "value": v_pref, "unit": "env-steps/s",
+        best = "prefetch_fused_policy" if v_fus > v_pref else "prefetch"
+        env_step = {"metric": "env_steps_per_sec", "value": max(v_pref, v_fus),
+                    "value_variant": best, "unit": "env-steps/s",
                     "parity": "unpinned (Connector.step semantics modelled on jumanji 0.2.2; no "
                               "reference fixture exists for them)",
                     "steps": args.env_steps, "auto_reset": True,
-                    "policy": "rbg_random_actions (masked uniform), one launch per step",
+                    "policy": "masked uniform (rbg_random_actions): its own launch per step "
+                              "(prefetch, inline_reset, no_auto_reset) or computed inside the "
+                              "step launch from the state's own mask (prefetch_fused_policy: "
+                              "rbg_connector_rollout_prefetch with n_steps = 1, bit-identical)",
                     "variants": {"prefetch": v_pref, "inline_reset": v_inl,
                                  "prefetch_fused_policy": v_fus, "no_auto_reset": v_off},
                     "ms_per_step": {"prefetch": k_pref, "inline_reset": k_inl,

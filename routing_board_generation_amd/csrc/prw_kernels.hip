@@ -293,6 +293,8 @@ struct EnvArgs {
   int mode;  // 0 reset (generate), 1 observe existing state, 2 step
   StashPtrs stash;  // all NULL when resets are always generated inline
   int tick, ready_delay;
+  const uint32_t *policy_keys;  // step only: non-NULL = the action comes from the masked-uniform
+  uint32_t policy_t;            // random policy (rbg_random_actions) of global step policy_t
 };
 
 // Row of the stash that holds the successor of the episode with State.key `key`, or -1.
@@ -471,7 +473,18 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
   }
 
   // ---- Connector.step --------------------------------------------------------------------------
-  const int act = lane < N ? a.action[(size_t)b * N + lane] : 0;
+  int act = 0;
+  if (a.policy_keys) {
+    // policy fused into the step launch: the mask rbg_random_actions would read from the previous
+    // timestep is the mask of the state just loaded
+    Key2 pk;
+    pk.a = a.policy_keys[2 * (size_t)b];
+    pk.b = a.policy_keys[2 * (size_t)b + 1];
+    if (lane < N)
+      act = random_policy_action(pk, a.policy_t, (uint32_t)lane, action_mask_bits(board, g, ag, lane));
+  } else if (lane < N) {
+    act = a.action[(size_t)b * N + lane];
+  }
   const StashProbe probe = stash_probe_issue(a.stash, a.B, b, lane);  // in flight during the step
   RowPrefetch pf;
   pf.row = -1;
@@ -1223,6 +1236,20 @@ int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_i
     if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_connector_rollout_prefetch")) return rc;
   a.tick = tick; a.ready_delay = ready_delay;
+  const bool wants_stats = stats && (stats->episodes || stats->connections_made ||
+                                     stats->unconnected_agent_steps || stats->final_connections ||
+                                     stats->final_path_length);
+  if (n_steps == 1 && last_timestep && last_timestep->obs_grid && !wants_stats) {
+    // "random policy + step" with the observation written: the HBM-bound shape of the per-step
+    // kernel (one env per wave, 16 waves per CU in flight), not the LDS-resident rollout's
+    EnvArgs e;
+    memset(&e, 0, sizeof(e));
+    if (int rc = make_geo(m, N, &e.g)) return rc;  // (the shuffle threshold depends on the lane count)
+    e.B = B; e.N = N; e.in = a.in; e.out = a.out; e.p = a.p; e.ts = a.ts; e.mode = kModeStep;
+    e.stash = a.stash; e.tick = tick; e.ready_delay = ready_delay;
+    e.policy_keys = policy_keys; e.policy_t = t0;
+    return launch_env(e, stream, "rbg_connector_rollout");
+  }
   const int envs_per_block = kWavesPerBlock * (kWaveSize / lpb);
   const dim3 grid((B + envs_per_block - 1) / envs_per_block), block(kBlock);
   const size_t lds = lds_bytes(a.g, lpb);
