@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 4
+#define RBG_ABI_VERSION 5
 
 #define RBG_E_NULL (-1)   /* a required pointer is NULL */
 #define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
@@ -111,6 +111,27 @@ int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
                      int32_t *solved_grid, int32_t *train_grid, int32_t *start, int32_t *target,
                      int32_t *position, int32_t *step_count, uint32_t *key_out, int32_t *iters,
                      void *stream);
+
+/* vmap(ParallelRandomWalkGenerator(m, N, stream="philox").__call__)(keys) -- OPT-IN, defined by
+ * this project: the walk of rbg_prw_generate driven by a counter-based Philox-4x32-10 stream
+ * instead of jax's Threefry key splitting (north_star's "Philox kernel replacing jax.random";
+ * SURVEY.md 8a-PRNG).  NOT the reference's random process: boards are valid and deterministic per
+ * key but differ from the reference's for the same key, and the only checker is this project's
+ * own CPU restatement of the stream (tests).  The stream: Philox-4x32-10 (Salmon et al., SC'11;
+ * M0 = 0xD2511F53, M1 = 0xCD9E8D57, W0 = 0x9E3779B9, W1 = 0xBB67AE85), key = the two words of the
+ * board's key, counter (c0, c1, c2, c3) with a domain tag in c3:
+ *   tag 1  start cells: the sort key of cell j is word j % 4 of philox(key, (j / 4, 0, 0, 1));
+ *          the N cells with the smallest (sort key, j), ascending, are the starts of agents 0..N-1;
+ *   tag 2  the walk: agent i's uniform at iteration t is word t % 4 of
+ *          philox(key, (t / 4, i, 0, 2)) through jax's float32 mantissa fill, and the choice is
+ *          jax's (cumsum of the availability flags, r = cum[-1] * (1 - u), first cum >= r);
+ *   tag 3  State.key (key_out) = words 0, 1 of philox(key, (0, 0, 0, 3)).
+ * Everything else (availability rule, max-join collision rule, head/target encodings, the
+ * training grid) is rbg_prw_generate's.  Same outputs as rbg_prw_generate(split_first = 1). */
+int rbg_prw_generate_philox(const uint32_t *keys, int B, int m, int N, int32_t *solved_grid,
+                            int32_t *train_grid, int32_t *start, int32_t *target,
+                            int32_t *position, int32_t *step_count, uint32_t *key_out,
+                            int32_t *iters, void *stream);
 
 /* vmap(SequentialRandomWalkBoard(m, m, N).generate)(keys)                   [split_first == 0]
  *   JAXI/sequential_random_walk.py:322-431 (generate + generate_starts_ends)

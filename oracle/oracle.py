@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libprw_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("prw_oracle.c", "seed_extension.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("prw_oracle.c", "seed_extension.c", "prw_philox.c", "Makefile")]
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libprw_oracle.so"])
@@ -406,3 +406,25 @@ def seed_extension_batch(keys, m, N, split_first=True, randomness=0.0, two_sided
     if rc != 0:
         raise ValueError("oracle_seed_extension_batch: bad arguments (rc=%d)" % rc)
     return st, solved, sweeps
+
+
+def philox4x32_10(key, ctr) -> np.ndarray:
+    key, ctr = _u32(key), _u32(ctr)
+    out = np.zeros(4, np.uint32)
+    lib().oracle_philox4x32_10(_p(key), _p(ctr), _p(out))
+    return out
+
+
+def prw_philox_batch(keys, m, N, threads=1):
+    """vmap(ParallelRandomWalkGenerator(m, N, stream="philox").__call__) over keys [B,2]
+    -> (state dict, solved [B,m,m], iters [B]).  Project-defined stream (oracle/prw_philox.c)."""
+    keys = _u32(keys).reshape(-1, 2)
+    B = keys.shape[0]
+    st = alloc_state(B, m, N)
+    solved = np.zeros((B, m, m), np.int32)
+    iters = np.zeros((B,), np.int32)
+    rc = lib().oracle_prw_philox_batch(_p(keys), B, m, N, *[_p(st[k]) for k in _STATE_ORDER],
+                                       _p(solved), _p(iters), threads)
+    if rc != 0:
+        raise ValueError("oracle_prw_philox_batch: bad arguments")
+    return st, solved, iters

@@ -13,6 +13,7 @@ from .offline_generation import BoardDatasetGenerator, BoardDatasetGeneratorJAX 
 from .board_generation.seed_extension import SeedExtensionBoard  # noqa: F401
 from .board_generation.sequential_random_walk import SequentialRandomWalkBoard  # noqa: F401
 from .online_generators import (Generator, ParallelRandomWalkGenerator,  # noqa: F401
+                                ParallelRandomWalkPhiloxGenerator,
                                 RandomSeedGenerator, SeedExtensionGenerator,
                                 SequentialRandomWalkGenerator, UniformRandomGenerator)
 from .random import PRNGKey, split  # noqa: F401

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
 HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
                "-std=c++17"]
 
@@ -62,6 +62,9 @@ SIGNATURES = {
     "rbg_prw_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rbg_prw_generate_philox": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rbg_seq_rw_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),

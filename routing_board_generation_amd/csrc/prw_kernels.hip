@@ -5,6 +5,7 @@
 //   rbg_walk.h     ParallelRandomWalk (one board per sub-wave of 16/32/64 lanes)
 //   rbg_env.h      Connector reset / step / observation pieces (one env per sub-wave)
 //   rbg_seqwalk.h  SequentialRandomWalk (one board per wavefront)
+//   rbg_walk_philox.h  the opt-in Philox stream of the walk (project-defined; N lanes per board)
 //   rbg_seedext.h  SeedExtension (one board per sub-wave; chain phase + event phase + exact BFS)
 // Common design:
 //   * a board lives in LDS as a "padded" image (2 wall rows above/below, 4 wall columns shared
@@ -30,6 +31,7 @@
 #include "rbg_env.h"
 #include "rbg_seqwalk.h"
 #include "rbg_seedext.h"
+#include "rbg_walk_philox.h"
 
 namespace {
 
@@ -162,6 +164,44 @@ __global__ __launch_bounds__(kBlock) void seq_rw_generate_kernel(GenArgs a) {
     if (a.key_out) *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(key.a, key.b);
     if (a.step_count) a.step_count[b] = 0;
     if (a.iters) a.iters[b] = attempts;
+  }
+}
+
+// ParallelRandomWalkGenerator(stream = "philox") (rbg_walk_philox.h): N lanes per board suffice
+template <int LPB>
+__global__ __launch_bounds__(kBlock) void prw_philox_generate_kernel(GenArgs a) {
+  constexpr int kSubs = SubWave<LPB>::kSubs;
+  const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int first = (blockIdx.x * kWavesPerBlock + wib) * kSubs;
+  if (first >= a.B) return;
+  const Geo g = a.g;
+  const bool valid = first + sw.h < a.B;
+  const int b = valid ? first + sw.h : first;
+  uint32_t *board = g_lds + (wib * kSubs + sw.h) * slab_words<LPB>(g);
+  uint32_t *W = board + board_words(g);
+  Key2 key;
+  key.a = a.keys[2 * (size_t)b];
+  key.b = a.keys[2 * (size_t)b + 1];
+  Walker w;
+  prw_walk_philox(sw, board, W, g, a.N, key, w);
+  if (!valid) return;
+  const size_t gofs = (size_t)b * g.n;
+  if (a.solved_grid) store_grid<LPB, false>(board, g, sw.l, a.solved_grid + gofs);
+  if (a.train_grid) store_grid<LPB, true>(board, g, sw.l, a.train_grid + gofs);
+  if (sw.l < a.N) {
+    const size_t o = ((size_t)b * a.N + sw.l) * 2;
+    *reinterpret_cast<int2 *>(&a.start[o]) = make_int2(w.r0, w.c0);
+    *reinterpret_cast<int2 *>(&a.target[o]) = make_int2(w.r, w.c);
+    if (a.position) *reinterpret_cast<int2 *>(&a.position[o]) = make_int2(w.r0, w.c0);
+  }
+  if (sw.l == 0) {
+    if (a.key_out) {  // State.key (tag 3)
+      const Philox4 p = philox4x32_10(key.a, key.b, 0u, 0u, 0u, 3u);
+      *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(p.w[0], p.w[1]);
+    }
+    if (a.step_count) a.step_count[b] = 0;
+    if (a.iters) a.iters[b] = w.iters;
   }
 }
 
@@ -945,6 +985,36 @@ int rbg_prw_generate(const uint32_t *keys, int B, int m, int N, int split_first,
     hipLaunchKernelGGL(prw_generate_kernel<64>, grid, block, lds, st, a);
   }
   return check_hip(hipGetLastError(), "rbg_prw_generate");
+}
+
+int rbg_prw_generate_philox(const uint32_t *keys, int B, int m, int N, int32_t *solved_grid,
+                            int32_t *train_grid, int32_t *start, int32_t *target,
+                            int32_t *position, int32_t *step_count, uint32_t *key_out,
+                            int32_t *iters, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_prw_generate_philox: B < 0");
+  GenArgs a;
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  int lpb = 16;  // lane i = agent i: N lanes per board
+  while (lpb < N || (lpb < kWaveSize && lds_bytes(a.g, lpb) > 64u * 1024u)) lpb *= 2;
+  if (int rc = make_geo(m, N, &a.g, N, lpb)) return rc;
+  if (B == 0) return 0;
+  if (!keys || !start || !target) return fail(RBG_E_NULL, "rbg_prw_generate_philox: NULL pointer");
+  if (int rc = check_align(a.g, solved_grid, train_grid, nullptr)) return rc;
+  a.keys = keys; a.B = B; a.N = N; a.split_first = 0;
+  a.solved_grid = solved_grid; a.train_grid = train_grid; a.start = start; a.target = target;
+  a.position = position; a.step_count = step_count; a.key_out = key_out; a.iters = iters;
+  const int boards_per_block = kWavesPerBlock * (kWaveSize / lpb);
+  const dim3 grid((B + boards_per_block - 1) / boards_per_block), block(kBlock);
+  const size_t lds = lds_bytes(a.g, lpb);
+  hipStream_t st = (hipStream_t)stream;
+  if (lpb == 16) {
+    hipLaunchKernelGGL(prw_philox_generate_kernel<16>, grid, block, lds, st, a);
+  } else if (lpb == 32) {
+    hipLaunchKernelGGL(prw_philox_generate_kernel<32>, grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL(prw_philox_generate_kernel<64>, grid, block, lds, st, a);
+  }
+  return check_hip(hipGetLastError(), "rbg_prw_generate_philox");
 }
 
 int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_first,

@@ -30,13 +30,15 @@ constexpr int kKeyRounds = 4;  // register-resident sort keys: 2 * kKeyRounds wo
 template <int LPB>
 __device__ __forceinline__ void shuffle_prefix(const SubWave<LPB> &sw, uint32_t *scratch,
                                                uint32_t *aux, const Geo &g, Key2 sub, int count,
-                                               uint32_t thr, int &sel0, int &sel1) {
+                                               uint32_t thr, int &sel0, int &sel1,
+                                               bool keys_ready = false) {
+  // keys_ready: `scratch` already holds the n sort keys (another stream than jax's made them)
   const uint32_t n = (uint32_t)g.n;
   const uint32_t half = (n + 1u) >> 1;
   const int l = sw.l;
   sel0 = sel1 = -1;
   // Threefry block j yields the keys of cells j (y0) and half + j (y1)
-  const bool in_regs = thr != 0u && half <= (uint32_t)(kKeyRounds * LPB);  // wave-uniform
+  const bool in_regs = !keys_ready && thr != 0u && half <= (uint32_t)(kKeyRounds * LPB);  // wave-uniform
   uint32_t klo[kKeyRounds], khi[kKeyRounds];
   if (in_regs) {
 #pragma unroll
@@ -52,7 +54,7 @@ __device__ __forceinline__ void shuffle_prefix(const SubWave<LPB> &sw, uint32_t 
         khi[k] = y.y;
       }
     }
-  } else {
+  } else if (!keys_ready) {
     for (uint32_t j = l; j < half; j += LPB) {
       const bool has_hi = half + j < n;
       const uint2 y = threefry_call(sub.a, sub.b, j, has_hi ? half + j : 0u);

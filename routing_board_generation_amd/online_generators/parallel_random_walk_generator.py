@@ -26,3 +26,21 @@ class ParallelRandomWalkGenerator(Generator):
               "position": out["position"], "key": out["key_out"],
               "step_count": out["step_count"]}
         return state_from_bufs(st, batched)
+
+
+class ParallelRandomWalkPhiloxGenerator(Generator):
+    """The same walk on a counter-based Philox-4x32-10 stream instead of jax's Threefry key
+    splitting (north_star's "Philox kernel replacing jax.random").  OPT-IN and
+    defined by this project: boards are valid, solvable and deterministic per key, but they are
+    NOT the reference's boards for that key -- the default `ParallelRandomWalkGenerator` is the
+    bit-exact one.  The stream is specified in include/rbg_prw.h.  A `Connector` built on it
+    resets through generator(key) + `rbg_connector_observe` (no fused auto-reset)."""
+
+    def __call__(self, key: torch.Tensor) -> State:
+        batched = key.dim() == 2
+        keys = key if batched else key[None]
+        out = ops.prw_generate_philox(keys.contiguous(), self.grid_size, self.num_agents)
+        st = {"grid": out["train_grid"], "start": out["start"], "target": out["target"],
+              "position": out["position"], "key": out["key_out"],
+              "step_count": out["step_count"]}
+        return state_from_bufs(st, batched)

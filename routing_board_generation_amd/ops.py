@@ -173,6 +173,31 @@ def prw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool, want_sol
     return o
 
 
+def prw_generate_philox(keys: torch.Tensor, m: int, N: int, want_solved: bool = False,
+                        want_train: bool = True, out: Optional[dict] = None):
+    """The walk on the opt-in Philox stream (project-defined; include/rbg_prw.h): dict(solved_grid?,
+    train_grid?, start, target, position, step_count, key_out, iters)."""
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    o = out if out is not None else {}
+    for name, shape, dt in (("start", (B, N, 2), torch.int32), ("target", (B, N, 2), torch.int32),
+                            ("position", (B, N, 2), torch.int32), ("step_count", (B,), torch.int32),
+                            ("key_out", (B, 2), torch.uint32), ("iters", (B,), torch.int32)):
+        if name not in o:
+            o[name] = torch.empty(shape, dtype=dt, device=dev)
+    if want_solved and "solved_grid" not in o:
+        o["solved_grid"] = torch.empty((B, m, m), **i32)
+    if want_train and "train_grid" not in o:
+        o["train_grid"] = torch.empty((B, m, m), **i32)
+    nat.check(nat.lib().rbg_prw_generate_philox(
+        keys.data_ptr(), B, m, N, _ptr(o.get("solved_grid")), _ptr(o.get("train_grid")),
+        o["start"].data_ptr(), o["target"].data_ptr(), o["position"].data_ptr(),
+        o["step_count"].data_ptr(), o["key_out"].data_ptr(), o["iters"].data_ptr(),
+        _stream(dev)), "rbg_prw_generate_philox")
+    return o
+
+
 def seq_rw_generate(keys: torch.Tensor, m: int, N: int, split_first: bool,
                     want_solved: bool = True, want_train: bool = True):
     """SequentialRandomWalk: dict(solved_grid?, train_grid?, start, target, position, step_count,

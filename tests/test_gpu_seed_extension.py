@@ -175,3 +175,42 @@ def test_seed_extension_argument_errors(rbg):
         ops.seed_extension_generate(keys, 10, 5, split_first=True, extension_iterations=-2)
     out = ops.seed_extension_generate(keys[:0], 10, 5, split_first=True)
     assert out["start"].shape == (0, 5, 2)
+
+
+# ------------------------------------------------------------------------------ Philox stream
+@pytest.mark.parametrize("m,N,B,seed", [(16, 10, 4096, 0), (8, 5, 257, 1), (10, 5, 100, 2),
+                                        (32, 20, 64, 3), (12, 33, 16, 4), (16, 64, 8, 5),
+                                        (5, 3, 64, 6), (7, 16, 33, 7), (2, 1, 5, 8), (40, 15, 8, 9)])
+def test_philox_stream_generator_matches_its_oracle(rbg, oracle, m, N, B, seed):
+    """The opt-in Philox stream (north_star) against ITS oracle, oracle/prw_philox.c
+    -- parity with the reference is neither claimed nor possible for it (a different random
+    process); what is checked is HIP == CPU restatement, bit for bit, and board validity."""
+    from helpers import check_solved_boards
+    from routing_board_generation_amd import ops
+
+    keys = _keys(rbg, seed, B)
+    out = ops.prw_generate_philox(keys, m, N, want_solved=True)
+    est, esolved, eiters = oracle.prw_philox_batch(to_np(keys), m, N, threads=16)
+    assert (to_np(out["iters"]) == eiters).all()
+    assert (to_np(out["solved_grid"]) == esolved).all()
+    got = {"grid": to_np(out["train_grid"]), "start": to_np(out["start"]),
+           "target": to_np(out["target"]), "position": to_np(out["position"]),
+           "key": to_np(out["key_out"]), "step_count": to_np(out["step_count"])}
+    assert_dicts_equal(got, est, f"philox {m}x{m}/{N}: ")
+    check_solved_boards(esolved, est["start"], est["target"])
+
+
+def test_philox_generator_class_and_env(rbg, oracle):
+    gen = rbg.ParallelRandomWalkPhiloxGenerator(10, 5)
+    keys = _keys(rbg, 3, 32)
+    state = gen(keys)
+    est, _, _ = oracle.prw_philox_batch(to_np(keys), 10, 5)
+    assert (to_np(state.grid) == est["grid"]).all() and (to_np(state.key) == est["key"]).all()
+    one = gen(keys[5])
+    assert one.grid.shape == (10, 10) and (to_np(one.grid) == est["grid"][5]).all()
+    # a different process from the reference's: same key, different board
+    ref = rbg.ParallelRandomWalkGenerator(10, 5)(keys)
+    assert not (to_np(ref.grid) == est["grid"]).all()
+    env = rbg.Connector(generator=gen)
+    st, ts = env.reset(keys[:8])
+    assert (to_np(st.grid) == est["grid"][:8]).all() and ts.observation.grid.shape == (8, 5, 10, 10)

@@ -373,3 +373,22 @@ def test_c1_boards_of_survey_appendix_b1(oracle):
     assert st["start"][0].tolist() == [[2, 6], [6, 7], [4, 7], [0, 4], [3, 1]]
     assert st["target"][0].tolist() == [[3, 7], [6, 3], [6, 1], [0, 7], [7, 7]]
     assert solved[0][7].tolist() == [13, 13, 13, 13, 13, 13, 13, 15]
+
+
+def test_philox4x32_10_known_answers(oracle):
+    """Random123's published known-answer vectors for philox4x32-10 (kat_vectors): the opt-in
+    stream's block function is the standard one."""
+    kat = [((0, 0), (0, 0, 0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 2, (0xffffffff,) * 4, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0xa4093822, 0x299f31d0), (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for key, ctr, exp in kat:
+        assert tuple(int(x) for x in oracle.philox4x32_10(key, ctr)) == exp
+
+
+def test_philox_stream_boards_are_valid(oracle):
+    from helpers import check_solved_boards
+    keys = oracle.split(oracle.prng_key(0), 512)
+    st, solved, iters = oracle.prw_philox_batch(keys, 16, 10, threads=4)
+    check_solved_boards(solved, st["start"], st["target"])
+    assert 20 < iters.mean() < 35  # the same walk: trip counts distributed like the jax stream's

@@ -12,13 +12,18 @@
 #define CHAIN(name, body)                                                            \
   __global__ void name(uint32_t *out, uint64_t *cycles) {                            \
     uint32_t x = threadIdx.x, y = threadIdx.x * 7 + 1, z = 0x9E3779B9u;              \
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();                            \
     const uint64_t t0 = __builtin_amdgcn_s_memtime();                                \
     for (int i = 0; i < 16; ++i) {                                                   \
       REP64(body)                                                                    \
     }                                                                                \
     const uint64_t t1 = __builtin_amdgcn_s_memtime();                                \
+    const uint64_t r1 = __builtin_amdgcn_s_memrealtime();                            \
     out[threadIdx.x] = x + y;                                                        \
-    if (threadIdx.x == 0) cycles[0] = t1 - t0;                                       \
+    if (threadIdx.x == 0) {                                                          \
+      cycles[0] = t1 - t0;                                                           \
+      cycles[1] = r1 - r0; /* 100 MHz ticks */                                       \
+    }                                                                                \
   }
 
 CHAIN(k_add, asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(z));)
@@ -39,13 +44,15 @@ CHAIN(k_dpp, asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] ro
 
 int main() {
   uint32_t *out;
-  uint64_t *cyc, h;
+  uint64_t *cyc, h[2];
   hipMalloc(&out, 64 * 4);
-  hipMalloc(&cyc, 8);
+  hipMalloc(&cyc, 16);
 #define RUN(k, per)                                                                  \
   for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, cyc); \
-  hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);                                      \
-  printf("%-22s %6.2f cycles per %s\n", #k, (double)h / (16.0 * 64.0), per);
+  hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);                                      \
+  printf("%-22s %6.2f s_memtime ticks = %6.2f ns per %s  (s_memtime runs at %.0f MHz)\n", #k, \
+         (double)h[0] / (16.0 * 64.0), (double)h[1] * 10.0 / (16.0 * 64.0), per,     \
+         (double)h[0] / ((double)h[1] * 0.01));
   RUN(k_add, "dependent v_add_u32")
   RUN(k_xor, "dependent v_xor_b32")
   RUN(k_alignbit, "dependent v_alignbit_b32")
