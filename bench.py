@@ -333,6 +333,9 @@ def all_configs():
         elif kind == "seq":
             f = lambda: ops.seq_rw_generate(keys, m, N, split_first=True, want_solved=False)  # noqa
             cf = lambda: O.seq_rw_generator_batch(keys.cpu().numpy(), m, N, threads=threads)  # noqa
+        elif kind == "philox":  # the opt-in Philox stream of the walk (not the reference's process)
+            f = lambda: ops.prw_generate_philox(keys, m, N)  # noqa
+            cf = lambda: O.prw_philox_batch(keys.cpu().numpy(), m, N, threads=threads)  # noqa
         else:  # SeedExtensionGenerator.__call__ (reference defaults)
             f = lambda: ops.seed_extension_generate(keys, m, N, split_first=True)  # noqa
             cf = lambda: O.seed_extension_batch(keys.cpu().numpy(), m, N, threads=threads)  # noqa
@@ -346,6 +349,9 @@ def all_configs():
     gen_row("C2 ParallelRandomWalk 16x16/10 B=4096", 16, 10, 4096)
     gen_row("C4 ParallelRandomWalk 32x32/20 B=4096 (one GPU's shard of 32768)", 32, 20, 4096)
     gen_row("C5 SequentialRandomWalk 16x16/10 B=4096", 16, 10, 4096, kind="seq")
+    gen_row("C2 shape on the opt-in Philox stream 16x16/10 B=4096", 16, 10, 4096, kind="philox")
+    gen_row("C2 shape on the opt-in Philox stream 16x16/10 B=65536", 16, 10, 65536, kind="philox")
+    gen_row("C2 ParallelRandomWalk 16x16/10 B=65536", 16, 10, 65536)
     gen_row("C5 SeedExtension 16x16/10 B=4096", 16, 10, 4096, kind="seed_ext")
     gen_row("ref SeedExtension 10x10/5 B=100 (notebook batch: 427 ms on JAX-CPU)", 10, 5, 100,
             kind="seed_ext")
@@ -542,6 +548,32 @@ def main() -> None:
                 "issue": issue_roofline("prw_generate_kernel", B, kernel_avg_ms),
                 "note": "latency-bound walk (serial dependent iterations per board): HBM fraction "
                         "reported for the record, the issue-based figure beside it; see DESIGN.md"}
+
+    # the opt-in Philox stream of the same walk (north_star / SURVEY 8a-PRNG): a different random
+    # process (not the reference's boards), so it is reported beside `value`, never as it
+    philox = None
+    if args.mode in ("all", "generator"):
+        p_out = ops.prw_generate_philox(keys, m, N)
+        p_steps = min(args.steps, 300)
+        for _ in range(5):
+            ops.prw_generate_philox(keys, m, N, out=p_out)
+        pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        pe0.record()
+        for _ in range(p_steps):
+            ops.prw_generate_philox(keys, m, N, out=p_out)
+        pe1.record()
+        barrier()
+        p_ms = pe0.elapsed_time(pe1) / p_steps
+        philox = {"value_per_gpu": B / (p_ms * 1e-3), "unit": "boards/s", "ms_per_step": p_ms,
+                  "steps": p_steps,
+                  "note": "rbg_prw_generate_philox: the same walk on a Philox-4x32-10 stream "
+                          "(project-defined, include/rbg_prw.h; its only checker is this "
+                          "project's CPU restatement). Four boards per wavefront, one Philox "
+                          "evaluation per agent every four iterations; at B = 4096 the launch is "
+                          "bounded by its longest board like the default path, at B = 65536 it "
+                          "runs 1.5x the default path's rate"}
+        del p_out
 
     pipelined = None
     if args.pipelined:
@@ -831,6 +863,8 @@ def main() -> None:
         }
         if peaks is not None:
             line["roofline"]["peak_measured"] = peaks
+        if philox is not None:
+            line["philox_stream"] = philox
         if pipelined is not None:
             line["pipelined"] = pipelined
         print(json.dumps(line), flush=True)
