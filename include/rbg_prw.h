@@ -162,7 +162,9 @@ int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_fir
  *                         default 1e23 means no limit: pass INT32_MAX)
  * Same outputs as rbg_prw_generate (start = the wires' POSITION cells, target = their TARGET
  * cells); solved_grid, when given, also triggers the final re-routing pass, which no other
- * output can see.  sweeps (nullable) int32 [B] = extension sweeps the board took.
+ * output can see.  sweeps (nullable) int32 [B] = extension sweeps that changed the board (a
+ * board none of whose ends can extend is finished; the reference sweeps it a few more times,
+ * until an un-flipped sweep lets its stopping comparison succeed, with no effect on any output).
  * extension_iterations == -1 (with split_first == 0): return_seeded_board(keys)
  * (seed_extension.py:93-147) -- the keys are the seed keys themselves and nothing is extended.
  * N <= (m / 2)^2 (the candidate seed cells). */

@@ -390,22 +390,25 @@ def randint_vec(key, n, lo, hi):
 
 
 def seed_extension_batch(keys, m, N, split_first=True, randomness=0.0, two_sided=True,
-                         extension_iterations=1, extension_steps=1e23, threads=1):
+                         extension_iterations=1, extension_steps=1e23, threads=1,
+                         return_live=False):
     """vmap(SeedExtensionGenerator(m, N).__call__) (split_first) or
     vmap(SeedExtensionBoard(m, m, N).generate_starts_ends) (not split_first) over keys [B,2]
-    -> (state dict, solved [B,m,m], sweeps [B])."""
+    -> (state dict, solved [B,m,m], sweeps [B]) (+ live sweeps [B] with return_live: the sweeps
+    that changed the board, which is what the HIP kernel runs and reports)."""
     keys = _u32(keys).reshape(-1, 2)
     B = keys.shape[0]
     st = alloc_state(B, m, N)
     solved = np.zeros((B, m, m), np.int32)
     sweeps = np.zeros((B,), np.int32)
+    live = np.zeros((B,), np.int32)
     rc = lib().oracle_seed_extension_batch(
         _p(keys), B, m, N, int(bool(split_first)), C.c_float(randomness), int(bool(two_sided)),
         int(extension_iterations), C.c_double(extension_steps),
-        *[_p(st[k]) for k in _STATE_ORDER], _p(solved), _p(sweeps), threads)
+        *[_p(st[k]) for k in _STATE_ORDER], _p(solved), _p(sweeps), _p(live), threads)
     if rc != 0:
         raise ValueError("oracle_seed_extension_batch: bad arguments (rc=%d)" % rc)
-    return st, solved, sweeps
+    return (st, solved, sweeps, live) if return_live else (st, solved, sweeps)
 
 
 def philox4x32_10(key, ctr) -> np.ndarray:

@@ -197,7 +197,7 @@ static int choice_true_false(const uint32_t key[2]) {
  * post_processor_utils_jax.py:24-195  extend_wires_jax.  Returns the number of while iterations.
  * ---------------------------------------------------------------------------------------- */
 static int extend_wires(int32_t *board, int m, const uint32_t key_in[2], float randomness,
-                        int two_sided, double extension_steps) {
+                        int two_sided, double extension_steps, int *live_sweeps) {
   const int cells = m * m;
   uint32_t key[2] = {key_in[0], key_in[1]};
   int32_t prev[SE_MAX_CELLS];
@@ -208,6 +208,8 @@ static int extend_wires(int32_t *board, int m, const uint32_t key_in[2], float r
   while (memcmp(prev, board, sizeof(int32_t) * (size_t)cells) != 0 &&
          (float)step_num < (float)extension_steps) {
     step_num += 1;
+    int32_t before[SE_MAX_CELLS]; /* (diagnostic only: did this sweep change the board?) */
+    memcpy(before, board, sizeof(int32_t) * (size_t)cells);
     uint32_t ks[6];
     oracle_split(key, 3, ks); /* :63 key, flipkey, flopkey */
     key[0] = ks[0];
@@ -266,6 +268,8 @@ static int extend_wires(int32_t *board, int m, const uint32_t key_in[2], float r
     }
     if (do_flip) flip_rows(board, m); /* :186-187 */
     if (do_flop) flip_cols(board, m);
+    if (live_sweeps && memcmp(before, board, sizeof(int32_t) * (size_t)cells) != 0)
+      *live_sweeps += 1;
   }
   return step_num;
 }
@@ -365,29 +369,34 @@ static int optimise_wire(const uint32_t key[2], int32_t *board, int m, int wire_
 
 /* ------------------------------------------------------------------------------------------
  * seed_extension.py:149-227  return_solved_board.  sweeps (nullable) = total while iterations
- * of extend_wires_jax over all extension iterations.
+ * of extend_wires_jax over all extension iterations; live_sweeps (nullable) = those of them that
+ * changed the board.  (Once a sweep changes nothing, no later one can -- which cells an endpoint
+ * may extend into does not depend on the frame -- and the reference only keeps drawing flips until
+ * an un-flipped sweep lets its comparison succeed: the HIP kernel stops there, see rbg_seedext.h.)
  * ---------------------------------------------------------------------------------------- */
 int oracle_seed_extension_solved_board(const uint32_t key_in[2], int m, int N, float randomness,
                                        int two_sided, int extension_iterations,
-                                       double extension_steps, int32_t *board, int32_t *sweeps) {
+                                       double extension_steps, int32_t *board, int32_t *sweeps,
+                                       int32_t *live_sweeps) {
   if (m < 2 || m > SE_MAX_SIDE || N < 1) return -1;
   uint32_t ks[6];
   oracle_split(key_in, 2, ks); /* :171 key, seedkey */
   uint32_t key[2] = {ks[0], ks[1]};
   if (return_seeded_board(&ks[2], m, N, board) != 0) return -1;
   int wires_on_board = N > (m * m) / 3 ? (m * m) / 3 : N; /* :60-63 */
-  int total = 0;
+  int total = 0, live = 0;
   for (int it = 0; it < extension_iterations; ++it) { /* :180-224, converged stays False */
     oracle_split(key, 3, ks); /* :189 key, extkey, optkey */
     key[0] = ks[0];
     key[1] = ks[1];
-    total += extend_wires(board, m, &ks[2], randomness, two_sided, extension_steps);
+    total += extend_wires(board, m, &ks[2], randomness, two_sided, extension_steps, &live);
     uint32_t optkeys[2 * (size_t)wires_on_board];
     oracle_split(&ks[4], wires_on_board, optkeys); /* :194 */
     for (int w = 0; w < wires_on_board; ++w) /* :199-208 */
       if (optimise_wire(&optkeys[2 * w], board, m, w) != 0) return -2;
   }
   if (sweeps) *sweeps = total;
+  if (live_sweeps) *live_sweeps = live; /* sweeps that changed the board */
   return 0;
 }
 
@@ -412,7 +421,7 @@ int oracle_seed_extension_generate(const uint32_t key_in[2], int m, int N, int s
                                    float randomness, int two_sided, int extension_iterations,
                                    double extension_steps, int32_t *solved, int32_t *train_grid,
                                    int32_t *start, int32_t *target, uint32_t *key_out,
-                                   int32_t *sweeps) {
+                                   int32_t *sweeps, int32_t *live_sweeps) {
   uint32_t key[2] = {key_in[0], key_in[1]};
   if (split_first) {
     uint32_t ks[4];
@@ -422,7 +431,8 @@ int oracle_seed_extension_generate(const uint32_t key_in[2], int m, int N, int s
   }
   int32_t board[SE_MAX_CELLS];
   int rc = oracle_seed_extension_solved_board(key, m, N, randomness, two_sided,
-                                              extension_iterations, extension_steps, board, sweeps);
+                                              extension_iterations, extension_steps, board, sweeps,
+                                              live_sweeps);
   if (rc != 0) return rc;
   for (int w = 0; w < N; ++w) {
     find_first(board, m, 3 * w + POSITION, &start[2 * w]);
@@ -446,7 +456,8 @@ int oracle_seed_extension_batch(const uint32_t *keys, int B, int m, int N, int s
                                 float randomness, int two_sided, int extension_iterations,
                                 double extension_steps, int32_t *grid, int32_t *step_count,
                                 int32_t *start, int32_t *target, int32_t *position,
-                                uint32_t *key_out, int32_t *solved, int32_t *sweeps, int threads) {
+                                uint32_t *key_out, int32_t *solved, int32_t *sweeps,
+                                int32_t *live_sweeps, int threads) {
   if (B < 0 || m < 2 || m > SE_MAX_SIDE || N < 1 || N > (m / 2) * (m / 2)) return -1;
   int bad = 0;
   (void)threads;
@@ -456,7 +467,8 @@ int oracle_seed_extension_batch(const uint32_t *keys, int B, int m, int N, int s
         &keys[2 * b], m, N, split_first, randomness, two_sided, extension_iterations,
         extension_steps, solved ? &solved[(size_t)b * m * m] : NULL,
         grid ? &grid[(size_t)b * m * m] : NULL, &start[(size_t)b * N * 2],
-        &target[(size_t)b * N * 2], key_out ? &key_out[2 * b] : NULL, sweeps ? &sweeps[b] : NULL);
+        &target[(size_t)b * N * 2], key_out ? &key_out[2 * b] : NULL, sweeps ? &sweeps[b] : NULL,
+        live_sweeps ? &live_sweeps[b] : NULL);
     bad |= rc != 0;
     if (position)
       memcpy(&position[(size_t)b * N * 2], &start[(size_t)b * N * 2], sizeof(int32_t) * 2 * N);

@@ -29,6 +29,9 @@
 //            stencil on the padded LDS board.
 // A sweep costs (m*m + margin) Threefry evaluations whatever the board holds, so the board with
 // the most sweeps bounds the launch; boards of one wave run in lock-step and idle once done.
+// Only sweeps that can change the board are run: a board whose endpoints are all stuck is
+// finished, although the reference keeps sweeping it until an un-flipped sweep comes up (the
+// loop in seed_extension_generate says why that is output-equivalent).
 // optimise_wire is a level-synchronous BFS whose FIFO order -- hence the reference's tie-breaking
 // between equally short paths -- is kept exactly: all (node, direction) pairs of a level claim
 // their neighbour with ds_min_u32(key = FIFO position * 4 + direction number); the smallest key
@@ -172,6 +175,23 @@ __device__ __noinline__ uint32_t se_idx_after(uint32_t ka, uint32_t kb, int rel)
   return y0 & 3u;
 }
 
+// Can the head/target at padded index P0 of the wire whose path value is `path` extend anywhere?
+// (poss_extension_list :80-97 non-empty: an empty neighbour that touches the wire only through
+// this cell.)  Which cells qualify does not depend on the sweep's frame.
+__device__ __forceinline__ bool se_can_extend(const uint32_t *board, int P0, uint32_t path, int S) {
+  bool any = false;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int step = d == 0 ? -S : d == 1 ? -1 : d == 2 ? S : 1;
+    const int perp = (d & 1) ? S : 1;
+    const int Q = P0 + step;
+    const uint32_t vq = board[Q];
+    const uint32_t a = board[Q + step], b = board[Q + perp], e = board[Q - perp];
+    any = any || (vq == 0u && !((a - path) < 3u || (b - path) < 3u || (e - path) < 3u));
+  }
+  return any;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The generator.  Lane w < N of the sub-wave owns wire w: (pr, pc) its POSITION cell, (tr, tc) its
 // TARGET cell.  On return the LDS board holds the solved board; returns the number of sweeps.
@@ -259,9 +279,29 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
 
     // ---- extend_wires_jax ---------------------------------------------------------------------
     Key2 K = extkey;
-    bool running = p.max_steps > 0;  // per board (sub-wave uniform)
+    bool running = true;  // per board (sub-wave uniform)
     int step_num = 0;
-    while (__ballot(running) != 0ull) {
+    while (true) {
+      // A board none of whose endpoints can extend is finished: no later sweep can change it
+      // (which cells an endpoint may enter does not depend on the frame), and all the reference
+      // still does with it is draw flips until an un-flipped sweep lets its comparison of the
+      // flipped "before" with the un-flipped "after" succeed (:51-70, :186-189) -- on average
+      // four more sweeps of m*m key-chain links each, a third of all the sweeps of a 16x16/10
+      // batch and most of those of its slowest board.  None of that reaches an output (the
+      // extension's key is local to extend_wires_jax), so the board stops here; `sweeps` counts
+      // the sweeps that changed the board.  Conversely a board with an endpoint that can extend
+      // always changes in the next sweep (the first such endpoint in sweep order still finds the
+      // board as it was), so the reference's comparison never succeeds on a live board.
+      if (running) {
+        bool can = false;
+        if (l < N) {
+          const uint32_t path = 3u * (uint32_t)l + 1u;
+          can = se_can_extend(board, pad_index(g, tr, tc), path, S) ||
+                (p.two_sided && se_can_extend(board, pad_index(g, pr, pc), path, S));
+        }
+        running = sw.ballot(can) != 0ull && step_num < p.max_steps;
+      }
+      if (__ballot(running) == 0ull) break;
       // :63-65  key, flipkey, flopkey = split(key, 3); do_flip = [True, False][randint(.., 2)]
       Key2 fk, pk;
       {
@@ -302,7 +342,6 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
       // frame -> physical: frame row fr is physical row (flip ? m-1-fr : fr), same for columns
       const int upF = flip ? S : -S, leftF = flop ? 1 : -1;
       const int d_step[4] = {upF, leftF, -upF, -leftF};  // poss order: up, left, down, right
-      bool changed = false;
       int cursor = 0;
       while (true) {
         uint32_t cand = 0xFFFFFFFFu;
@@ -384,29 +423,12 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
               pc += dc;
             }
           }
-          changed = true;
         }
         if (act) cursor = s + 1;
         wave_lds_fence();
       }
 
-      // ---- stopping rule :51-55: prev_layout (flipped frame, before) == board_layout (after)
-      // A sweep that moved something added a cell, so only an unchanged board can compare
-      // equal, and then only if it is its own mirror image under this sweep's flip/flop.
-      if (running) {
-        ++step_num;
-        bool same = !changed;
-        if (same && (flip || flop)) {
-          bool diff = false;
-          for (int idx = l; idx < n; idx += LPB) {
-            const int rr = div_m(g, idx), cc = idx - rr * m;
-            diff = diff || board[pad_index(g, rr, cc)] !=
-                               board[pad_index(g, flip ? m - 1 - rr : rr, flop ? m - 1 - cc : cc)];
-          }
-          same = sw.ballot(diff) == 0ull;
-        }
-        running = !same && step_num < p.max_steps;
-      }
+      if (running) ++step_num;  // (this sweep changed the board: see the top of the loop)
     }
     total_sweeps += step_num;
 
