@@ -569,10 +569,9 @@ def main() -> None:
                   "steps": p_steps,
                   "note": "rbg_prw_generate_philox: the same walk on a Philox-4x32-10 stream "
                           "(project-defined, include/rbg_prw.h; its only checker is this "
-                          "project's CPU restatement). Four boards per wavefront, one Philox "
-                          "evaluation per agent every four iterations; at B = 4096 the launch is "
-                          "bounded by its longest board like the default path, at B = 65536 it "
-                          "runs 1.5x the default path's rate"}
+                          "project's CPU restatement). One Philox evaluation per agent every "
+                          "four iterations, no key chain: ~100 instructions per walk iteration "
+                          "instead of 156"}
         del p_out
 
     pipelined = None

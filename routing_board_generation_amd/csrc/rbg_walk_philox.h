@@ -9,8 +9,9 @@
 // and board (split(k, N), N uniforms, the key chain), which is what sizes the default path's
 // sub-waves (2N + 2 lanes) and its three-stage lane pipeline.  Here agent i's uniform at
 // iteration t is word t % 4 of philox(key, (t / 4, i, 0, 2)): one evaluation per agent lane every
-// FOUR iterations, no chain, no LDS scratch -- so a board needs only N lanes (four 16x16/10 boards
-// per wavefront instead of two) and an iteration ~100 instructions instead of 156.
+// FOUR iterations, no chain, no LDS scratch -- so a board needs only N lanes (up to four 16x16/10
+// boards per wavefront instead of two; the host packs two when the batch is small, see
+// rbg_prw_generate_philox) and an iteration ~100 instructions instead of 156.
 #pragma once
 #include "rbg_walk.h"
 
