@@ -495,7 +495,7 @@ class StepLoop:
                  time_limit: int = 50, timestep_reward: float = -0.03,
                  connected_reward: float = 0.1, refill_every: int = 0,
                  fuse_policy: bool = False, auto_reset: bool = True,
-                 serial_refill: bool = True) -> None:
+                 serial_refill: bool = True, stash_depth: int = 1) -> None:
         B, m, _ = state["grid"].shape
         N = state["start"].shape[1]
         dev = state["grid"].device
@@ -512,7 +512,8 @@ class StepLoop:
         self._main = C.c_void_p(self._main_stream.cuda_stream)
         self.K = max(0, int(refill_every))
         self.fuse_policy = bool(fuse_policy)  # policy + step in ONE launch (rollout of 1 step)
-        self._epochs = EpochStash(B, m, N, dev, self.K, serial=serial_refill) if self.K else None
+        self._epochs = (EpochStash(B, m, N, dev, self.K, serial=serial_refill, depth=stash_depth)
+                        if self.K else None)
         if self.K:
             self.stash, self._h = self._epochs.stash, self._epochs.struct
 
