@@ -430,6 +430,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle", type=float, default=0.3,
+                    help="seconds of untimed launches before the warm-up steps (device clocks "
+                         "and caches at steady state); 0 = none")
     ap.add_argument("--env-steps", type=int, default=300,
                     help="env steps of the secondary Connector rollout measurement (0 = skip)")
     ap.add_argument("--rehearse-single-gpu", action="store_true",
@@ -507,10 +510,20 @@ def main() -> None:
     out = ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_train=True,
                            want_state=True, want_iters=True)
 
-    def step():
-        ops.prw_generate(keys, m, N, split_first=True, want_solved=False, want_train=True,
-                         want_state=True, want_iters=True, out=out)
+    # one step = one launch of the generator into the same output buffers; the launch is bound
+    # once (ops.prw_generate_launcher) because the per-call tensor checks of ops.prw_generate cost
+    # the host as much as the kernel takes, and a short run would time Python instead of the GPU
+    step = ops.prw_generate_launcher(keys, m, N, True, out)
 
+    # Settle the device before the W warm-up steps: a fresh process's first launches run at the
+    # idle clock and pay first-use costs (code object upload, caches), which a short run (the
+    # driver uses 20 steps after 5 warm-ups) would otherwise time instead of the steady state:
+    # 38.4 instead of 35.7 us per launch.  Untimed, like the warm-up steps themselves.
+    settle_until = time.perf_counter() + args.settle
+    while time.perf_counter() < settle_until:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     # ---------------------------------------------------------------- timed region
@@ -519,6 +532,8 @@ def main() -> None:
     # stack, comparable to the kernel itself.  Average launch duration = event span / K; it
     # includes the ~1-2 us dependent-launch gap, so it can only overstate the kernel time.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()  # torch creates a HIP event at its first record(): ~85 us each, which must not
+    ev1.record()  # land in a timed region of 20 steps (0.7 ms)
     barrier()
     t0 = time.perf_counter()
     ev0.record()
