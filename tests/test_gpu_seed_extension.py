@@ -217,3 +217,24 @@ def test_philox_generator_class_and_env(rbg, oracle):
     env = rbg.Connector(generator=gen)
     st, ts = env.reset(keys[:8])
     assert (to_np(st.grid) == est["grid"][:8]).all() and ts.observation.grid.shape == (8, 5, 10, 10)
+
+
+def test_shard_invariance_of_the_other_generators(rbg):
+    """the boards for keys[a:b] are the same whether they are produced inside the
+    full batch or as a shard of their own (what batch sharding over GPUs relies on), for the
+    generators beside the headline one; ragged shard sizes on purpose."""
+    from routing_board_generation_amd import ops
+
+    keys = _keys(rbg, 77, 1000)
+    runs = {
+        "seed_extension": lambda k: ops.seed_extension_generate(k, 16, 10, split_first=True,
+                                                                want_solved=True),
+        "philox": lambda k: ops.prw_generate_philox(k, 16, 10, want_solved=True),
+        "sequential": lambda k: ops.seq_rw_generate(k, 16, 10, split_first=True),
+    }
+    for name, fn in runs.items():
+        full = fn(keys)
+        for lo, hi in ((0, 125), (125, 126), (126, 513), (513, 1000)):
+            part = fn(keys[lo:hi].contiguous())
+            for f in ("solved_grid", "train_grid", "start", "target", "key_out"):
+                assert (to_np(part[f]) == to_np(full[f])[lo:hi]).all(), (name, f, lo, hi)
