@@ -49,6 +49,8 @@ def probe_times():
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
                           ["-DRBG_PROBE_STEP_TIMES", "-o", so, nat.SRC_PATH])
     lib = C.CDLL(so)
+    for name, (restype, argtypes) in nat.SIGNATURES.items():
+        getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
     for B in (4096, 16384):
         keys = rbg.split(rbg.PRNGKey(0), B)
         st, ts = ops.connector_reset(keys, m, N)
@@ -117,6 +119,8 @@ def probe_gaps():
         subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
                               flags[0].split() + ["-o", so, nat.SRC_PATH])
         lib = C.CDLL(so)
+        for name, (restype, argtypes) in nat.SIGNATURES.items():
+            getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
         print(f"probe build with {flags[0]}")
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     out = torch.empty((4, 2), dtype=torch.uint32, device="cuda")
@@ -166,3 +170,51 @@ def probe_gaps():
 
 if __name__ == "__main__" and "--gaps" in sys.argv:
     probe_gaps()
+
+
+def probe_reset_waves():
+    """Timeline of ONE step launch of a running auto-reset rollout (stash on): when do the waves
+    that restart an episode finish, compared with the others?  (probe build, see probe_times)"""
+    import ctypes as C
+    import subprocess
+
+    import numpy as np
+
+    from routing_board_generation_amd import _native as nat
+
+    so = os.path.join(ROOT, "gpurun_out", "librbg_probe_step_times.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                          ["-DRBG_PROBE_STEP_TIMES", "-o", so, nat.SRC_PATH])
+    lib = C.CDLL(so)
+    for name, (restype, argtypes) in nat.SIGNATURES.items():  # (plain ints would be truncated)
+        getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+    B = 4096
+    keys = rbg.split(rbg.PRNGKey(0), B)
+    st, ts = ops.alloc_state(B, m, N, "cuda"), ops.alloc_timestep(B, m, N, "cuda")
+    loop = ops.StepLoop(st, ts, keys, refill_every=16)
+    loop.reset(keys)
+    for t in range(150):
+        loop.step(t)
+    torch.cuda.synchronize()
+    loop._lib = lib  # the next launches come from the probe build
+    for t in range(150, 154):
+        loop.step(t)
+        torch.cuda.synchronize()
+        t0 = ts["num_connections"].cpu().numpy().astype(np.uint32)
+        t1 = ts["total_path_length"].cpu().numpy().astype(np.uint32)
+        last = ts["step_type"].cpu().numpy() == 2
+        base = t0.min()
+        start = (t0 - base).astype(np.int64) * 10
+        end = (t1 - base).astype(np.int64) * 10
+        print(f"step {t}: {int(last.sum())} restarting waves; launch span {end.max() / 1e3:.2f} us; "
+              f"others end p50 {np.percentile(end[~last], 50) / 1e3:.2f} p99 "
+              f"{np.percentile(end[~last], 99) / 1e3:.2f} max {end[~last].max() / 1e3:.2f}; "
+              f"restarting end p50 {np.percentile(end[last], 50) / 1e3:.2f} max "
+              f"{end[last].max() / 1e3:.2f}; their duration p50 "
+              f"{np.percentile((end - start)[last], 50) / 1e3:.2f} vs "
+              f"{np.percentile((end - start)[~last], 50) / 1e3:.2f} us")
+
+
+if __name__ == "__main__" and "--resets" in sys.argv:
+    probe_reset_waves()
