@@ -7,6 +7,8 @@ Parity unpinned (oracle <-> HIP only): randomness > 0, two_sided=False, extensio
 and the solved boards (optimise_wire never moves an endpoint, so no golden of the reference sees
 it); the single-board cell 10 of the notebook is stale (see tests/test_oracle_goldens.py).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -240,3 +242,41 @@ def test_shard_invariance_of_the_other_generators(rbg):
             part = fn(keys[lo:hi].contiguous())
             for f in ("solved_grid", "train_grid", "start", "target", "key_out"):
                 assert (to_np(part[f]) == to_np(full[f])[lo:hi]).all(), (name, f, lo, hi)
+
+
+def test_seed_extension_tries_beyond_the_prepared_chain(rbg, oracle, tmp_path):
+    """A cell's tries read the direction numbers phase A prepared for chain positions up to
+    n + RBG_SE_MARGIN; beyond that a slow exact path recomputes from K_n.  With the default margin
+    that path is rare: a build with margin 0 (compiled here, on the GPU box) takes it for every
+    try that runs past the last cell, and must still reproduce the oracle bit for bit."""
+    import ctypes as C
+    import subprocess
+
+    import torch
+
+    from routing_board_generation_amd import _native as nat
+
+    so = str(tmp_path / "librbg_margin0.so")
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                          ["-DRBG_SE_MARGIN=0", "-o", so, nat.SRC_PATH])
+    lib = C.CDLL(so)
+    for name, (restype, argtypes) in nat.SIGNATURES.items():
+        getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+    for (m, N, B, seed, randomness) in ((8, 16, 512, 31, 1.0), (10, 5, 1024, 32, 0.0),
+                                        (5, 4, 256, 33, 0.5)):
+        keys = _keys(rbg, seed, B)
+        i32 = dict(dtype=torch.int32, device="cuda")
+        solved, train = torch.empty((B, m, m), **i32), torch.empty((B, m, m), **i32)
+        start, target = torch.empty((B, N, 2), **i32), torch.empty((B, N, 2), **i32)
+        sweeps = torch.empty((B,), **i32)
+        rc = lib.rbg_seed_extension_generate(
+            keys.data_ptr(), B, m, N, 1, randomness, 1, 2, 2 ** 31 - 1, solved.data_ptr(),
+            train.data_ptr(), start.data_ptr(), target.data_ptr(), None, None, None,
+            sweeps.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.rbg_last_error()
+        est, esolved, _, elive = oracle.seed_extension_batch(
+            to_np(keys), m, N, randomness=randomness, extension_iterations=2, threads=16,
+            return_live=True)
+        assert (to_np(solved) == esolved).all() and (to_np(train) == est["grid"]).all()
+        assert (to_np(start) == est["start"]).all() and (to_np(target) == est["target"]).all()
+        assert (to_np(sweeps) == elive).all()
