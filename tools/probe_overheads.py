@@ -1,5 +1,13 @@
-import sys, time, torch
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Developer probe: host and synchronisation overheads around a short timed region (what a
+20-step bench run pays besides the kernels)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import routing_board_generation_amd as rbg
 from routing_board_generation_amd import ops
 dev=torch.device('cuda',0)

@@ -1,5 +1,12 @@
-import sys, torch
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Developer probe: the generator on the opt-in Philox stream against the default (jax Threefry)
+path, per batch size; --flags=... also times a probe build."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import routing_board_generation_amd as rbg
 from routing_board_generation_amd import ops
 def timed(fn, reps):
@@ -13,7 +20,7 @@ import ctypes as C, os, subprocess
 from routing_board_generation_amd import _native as nat
 libs=[("lpb16", nat.lib())]
 for fl in [a[8:] for a in sys.argv if a.startswith("--flags=")]:
-    so=os.path.join("/root/repo/gpurun_out","librbg_probe_philox.so")
+    so=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "librbg_probe_philox.so")
     subprocess.check_call([os.environ.get("HIPCC","/opt/rocm/bin/hipcc")]+nat.HIPCC_FLAGS+fl.split()+["-o",so,nat.SRC_PATH])
     lib=C.CDLL(so)
     for name,(rt,at) in nat.SIGNATURES.items(): getattr(lib,name).restype,getattr(lib,name).argtypes=rt,at
