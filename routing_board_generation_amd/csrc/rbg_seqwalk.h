@@ -34,9 +34,10 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 //
 // Retries without redundant work.  Every attempt restarts from the SAME key, so an attempt with
 // limit L - 1 replays the attempt with limit L exactly until some wire would have taken its L-th
-// step.  Hence (a) an attempt can stop at its first failing wire (the board is discarded), and
-// (b) if the wires before that one took at most s_max steps, every limit >= s_max fails the same
-// way: the next attempt that can differ has limit s_max - 1.  The reported attempt number is the
+// step.  Hence (a) an attempt can stop at its first failing wire (the board is discarded), (b)
+// if the wires before that one took at most s_max steps, every limit >= s_max fails the same
+// way: the next attempt that can differ has limit s_max - 1, and (c) that attempt need not
+// replay the common prefix either (see "Resuming" below).  The reported attempt number is the
 // one the reference's loop would have reached.
 //
 // Per step ONE Threefry evaluation serves two stages: lanes 0..3 draw the candidates' uniforms
@@ -60,15 +61,31 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, in
   const uint32_t c1 = lane < 4 ? (half_step + cblk < total_step ? half_step + cblk : 0u)
                                : (uint32_t)(lane & 1) + 2u;
 
-  int limit = 2 * m - 1;
+  // Resuming instead of replaying.  Attempt L - 1 replays attempt L up to the first wire w* that
+  // took more than L - 1 steps, and there it only stops one step earlier: the state to continue
+  // from is the failed attempt's own state with the wires after w* erased and w*'s LAST step
+  // undone (its last cell emptied, the cell before it the TARGET again, the key the one it had
+  // before that step's split).  Lane w keeps what that takes for wire w (last two cells, key
+  // before the last step); a wire that has already been cut once cannot be cut again from the
+  // record, and then the attempt replays from the start as the reference does.
+  int rec_steps = 0, rec_last = 0, rec_prev = 0;
+  Key2 rec_key = {0u, 0u};
+  bool rec_valid = false;
+  int limit = 2 * m - 1, w_begin = 0, s_max = 0;
+  Key2 key = key0;
+  bool fresh = true;
   while (limit >= 0) {
     const int attempt = 2 * m - limit;
-    board_clear<64>(board, g, lane);
-    Key2 key = key0;  // every retry starts from the same key (:347-355)
+    if (fresh) {
+      board_clear<64>(board, g, lane);
+      key = key0;  // every retry starts from the same key (:347-355)
+      s_max = 0;   // most steps taken by a wire of this attempt
+      w_begin = 0;
+      first_cell = last_cell = 0;
+    }
     bool success = true;
-    int s_max = 0;  // most steps taken by a wire of this attempt
-    first_cell = last_cell = 0;
-    for (int w = 0; w < N && success; ++w) {
+    int w = w_begin;
+    for (; w < N; ++w) {
       const uint32_t head = 3u * (uint32_t)w + 2u, path = head - 1u, tail = head + 1u;
       // add_agents: key, subkey = split(key) (the new key is dropped); pick_start(subkey):
       // key, subkey = split(key) -- the tuple carries THAT key from here on
@@ -108,7 +125,8 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, in
       // pipeline prologue: (key_next, step_key) = split(key)
       Key2 key_next, step_key;
       split2_lanes(sw, key, key_next, step_key);
-      int steps = 0;
+      int steps = 0, prevP = P;
+      Key2 key_before = key;  // the key before the last committed step
       for (; steps < limit; ++steps) {
         // lane d < 4 evaluates candidate d: empty, and touching this wire at most once
         const int Q = P + dP;
@@ -123,6 +141,7 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, in
         const uint32_t amask = (uint32_t)__ballot(avail) & 0xFu;
         if (amask == 0u) break;  // can_step == False now and for every later trip of the loop
         // one_step: key, subkey = split(key) is committed; choice over the padded candidates
+        key_before = key;
         key = key_next;
         key_next.a = __builtin_amdgcn_readlane(y.x, 4);
         key_next.b = __builtin_amdgcn_readlane(y.x, 5);
@@ -144,6 +163,7 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, in
           board[P + stepP] = tail;  // the new cell is the wire's TARGET ...
           board[P] = path;          // ... the old one becomes PATH
         }
+        prevP = P;
         P += stepP;
         wave_lds_fence();
       }
@@ -160,12 +180,49 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, in
         first_cell = r * m + c;
         unpad_index(g, P, r, c);
         last_cell = r * m + c;
+        rec_steps = steps;
+        rec_last = P;
+        rec_prev = prevP;
+        rec_key = key_before;
+        rec_valid = steps >= 2;
       }
     }
     if (success) return attempt;
-    // the wires before the failing one replay identically while limit >= s_max
-    limit = (s_max - 1 < limit - 1) ? s_max - 1 : limit - 1;
+    // `w` is the wire that failed; the wires before it replay identically while limit >= s_max
+    limit = s_max - 1;  // (s_max <= the old limit)
     if (limit < 1) break;  // limit 0 lets no wire move: every remaining attempt fails
+    // the first wire that took s_max steps is the one the next attempt cuts
+    const int ws = __builtin_amdgcn_readfirstlane(
+        (int)__ffsll((long long)__ballot(lane < w && rec_steps == s_max)) - 1);
+    fresh = ws < 0 || __builtin_amdgcn_readlane((int)rec_valid, ws) == 0;
+    if (!fresh) {
+      const int lastP = __builtin_amdgcn_readlane(rec_last, ws);
+      const int prevP = __builtin_amdgcn_readlane(rec_prev, ws);
+      key.a = (uint32_t)__builtin_amdgcn_readlane((int)rec_key.a, ws);
+      key.b = (uint32_t)__builtin_amdgcn_readlane((int)rec_key.b, ws);
+      const uint32_t first_gone = 3u * (uint32_t)(ws + 1) + 1u;  // smallest value of a later wire
+      for (int idx = lane; idx < g.n; idx += kWaveSize) {
+        const int r = div_m(g, idx);
+        const int p = pad_index(g, r, idx - r * m);
+        if (board[p] >= first_gone) board[p] = 0u;
+      }
+      wave_lds_fence();
+      if (lane == 0) {
+        board[lastP] = 0u;                              // the step that is taken back ...
+        board[prevP] = 3u * (uint32_t)ws + 3u;          // ... leaves the TARGET one cell earlier
+      }
+      wave_lds_fence();
+      if (lane == ws) {
+        int r, c;
+        unpad_index(g, prevP, r, c);
+        last_cell = r * m + c;
+        rec_steps = limit;
+        rec_last = prevP;
+        rec_valid = false;
+      }
+      w_begin = ws + 1;
+      s_max = limit;  // wire ws has `limit` steps now, the wires before it fewer than s_max
+    }
   }
   board_clear<64>(board, g, lane);
   first_cell = last_cell = 0;
