@@ -501,6 +501,35 @@ def test_sequential_random_walk_matches_oracle(rbg, oracle, m, N, B, seed):
     assert_dicts_equal(got, est, f"seq_rw {m}x{m}/{N}: ")
 
 
+SEQ_SWEEP = [  # (m, N, log2 B at scale 1): sparse boards (one attempt), dense ones (most retries
+    # resume from the cut wire, some replay, some boards fail for good), odd cell counts
+    (16, 10, 14), (10, 5, 13), (8, 8, 13), (6, 5, 13), (10, 9, 12), (16, 14, 12), (5, 6, 12),
+    (7, 7, 12), (12, 12, 11), (24, 20, 10), (9, 4, 12), (40, 30, 7),
+]
+
+
+@pytest.mark.parametrize("m,N,log2b", SEQ_SWEEP)
+def test_many_sequential_boards_match_oracle(rbg, oracle, m, N, log2b):
+    """The retry paths of the kernel (resume from the cut wire / replay when that wire was cut
+    before / give up) are taken by a few boards in a hundred: large samples, dense shapes.
+    RBG_SWEEP_SCALE multiplies the batch sizes."""
+    import os
+
+    from routing_board_generation_amd import ops
+
+    B = (1 << log2b) * int(os.environ.get("RBG_SWEEP_SCALE", "1"))
+    for lo in range(0, B, 32768):
+        keys = _keys(rbg, 2000 + m * 64 + N + lo, min(32768, B - lo))
+        out = ops.seq_rw_generate(keys, m, N, split_first=True)
+        est, esolved, eatt = oracle.seq_rw_generator_batch(to_np(keys), m, N, threads=16)
+        assert (to_np(out["attempts"]) == eatt).all()
+        assert (to_np(out["solved_grid"]) == esolved).all()
+        got = {"grid": to_np(out["train_grid"]), "start": to_np(out["start"]),
+               "target": to_np(out["target"]), "position": to_np(out["position"]),
+               "key": to_np(out["key_out"]), "step_count": to_np(out["step_count"])}
+        assert_dicts_equal(got, est, f"seq_rw {m}x{m}/{N}: ")
+
+
 def test_sequential_random_walk_board_api(rbg, oracle):
     board = rbg.SequentialRandomWalkBoard(10, 10, 5)
     keys = _keys(rbg, 9, 16)

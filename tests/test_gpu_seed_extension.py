@@ -111,6 +111,31 @@ def test_seed_extension_matches_oracle(rbg, oracle, m, N, B, seed, kw):
     _compare(out2, est, esolved, esweeps, f"seed extension (no solved) {m}x{m}/{N} {kw}")
 
 
+SE_SWEEP = [  # (m, N, log2 B at scale 1, kwargs): every sub-wave width, all option combinations
+    (16, 10, 13, dict()), (10, 5, 13, dict(randomness=1.0, two_sided=False)),
+    (10, 5, 12, dict(randomness=0.85, extension_iterations=3)), (8, 16, 12, dict(randomness=0.3)),
+    (12, 20, 11, dict(randomness=0.2, extension_iterations=2)), (16, 40, 9, dict(randomness=0.6)),
+    (7, 4, 12, dict(randomness=0.5, two_sided=False, extension_iterations=2)),
+    (20, 12, 10, dict(randomness=0.95)), (32, 20, 8, dict(randomness=0.4)),
+    (5, 3, 12, dict(randomness=1.0)), (16, 10, 11, dict(extension_steps=3, randomness=0.5)),
+]
+
+
+@pytest.mark.parametrize("m,N,log2b,kw", SE_SWEEP)
+def test_many_seed_extension_boards_match_oracle(rbg, oracle, m, N, log2b, kw):
+    """Rare paths (tries that run past the prepared chain, boards that are their own mirror image,
+    wires boxed in by their own path) need large samples.  RBG_SWEEP_SCALE multiplies them."""
+    from routing_board_generation_amd import ops
+
+    B = (1 << log2b) * int(os.environ.get("RBG_SWEEP_SCALE", "1"))
+    for lo in range(0, B, 16384):
+        keys = _keys(rbg, 3000 + m * 64 + N + lo, min(16384, B - lo))
+        out = ops.seed_extension_generate(keys, m, N, split_first=True, want_solved=True, **kw)
+        est, esolved, _, esweeps = oracle.seed_extension_batch(to_np(keys), m, N, threads=16,
+                                                               return_live=True, **kw)
+        _compare(out, est, esolved, esweeps, f"seed extension sweep {m}x{m}/{N} {kw}")
+
+
 def test_seed_extension_board_api(rbg, oracle):
     """SeedExtensionBoard methods (seed_extension.py:93-304) and the registry entry
     (interface/board_generator_interface.py:64)."""
