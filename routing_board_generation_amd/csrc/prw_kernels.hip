@@ -52,9 +52,14 @@ struct GenArgs {
   int32_t *step_count;
   uint32_t *key_out;
   int32_t *iters;
+  int seq_hist = 0;  // SequentialRandomWalk: LDS words of step history per board (0 = none)
 };
 
 extern __shared__ __attribute__((aligned(16))) uint32_t g_lds[];
+
+#ifndef RBG_SEQ_HISTORY_BYTES
+#define RBG_SEQ_HISTORY_BYTES (40 * 1024)  // per workgroup, boards included; 0 = never (tests)
+#endif
 
 // LPB lanes per board: 64 / LPB boards share one wavefront (the stencil keeps N lanes busy and
 // the Threefry pipeline 2N + 2, so small N would leave most of a wave idle).
@@ -142,7 +147,10 @@ __global__ __launch_bounds__(kBlock) void seq_rw_generate_kernel(GenArgs a) {
     split2_lanes(sw, key, key, unused);
   }
   int first_cell, last_cell;
-  const int attempts = seq_rw_generate(board, g, a.N, key, lane, first_cell, last_cell);
+  uint32_t *hist = a.seq_hist > 0
+                       ? g_lds + kWavesPerBlock * slab_words<64>(g) + wib * a.seq_hist
+                       : nullptr;
+  const int attempts = seq_rw_generate(board, hist, g, a.N, key, lane, first_cell, last_cell);
   const size_t gofs = (size_t)b * g.n;
   if (a.solved_grid) store_grid<64, false>(board, g, lane, a.solved_grid + gofs);
   if (attempts == 0 && lane == 0) {
@@ -1035,8 +1043,16 @@ int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_fir
   a.keys = keys; a.B = B; a.N = N; a.split_first = split_first != 0;
   a.solved_grid = solved_grid; a.train_grid = train_grid; a.start = start; a.target = target;
   a.position = position; a.step_count = step_count; a.key_out = key_out; a.iters = attempts;
+  // step history for resumed retries (rbg_seqwalk.h) when it leaves room for >= 4 workgroups per CU
+  const size_t hist_words = (size_t)N * (size_t)(2 * m - 1) * 4;
+  size_t lds = lds_bytes(a.g);
+  a.seq_hist = 0;
+  if (lds + kWavesPerBlock * hist_words * sizeof(uint32_t) <= (size_t)RBG_SEQ_HISTORY_BYTES) {
+    a.seq_hist = (int)hist_words;
+    lds += kWavesPerBlock * hist_words * sizeof(uint32_t);
+  }
   hipLaunchKernelGGL(seq_rw_generate_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
-                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+                     dim3(kBlock), lds, (hipStream_t)stream, a);
   return check_hip(hipGetLastError(), "rbg_seq_rw_generate");
 }
 

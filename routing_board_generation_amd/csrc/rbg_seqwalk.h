@@ -11,7 +11,7 @@
 //     random_bits(key, m*m), spread over the lanes, winner by a wave-wide 64-bit max;
 //   * one_step: the same draw over [up, down, left, right] (+ padding to rows + 1 entries, which
 //     only matters for the counter layout of random_bits); lanes 0..3 evaluate one candidate each
-//     (stencil + Threefry), the winner is picked on scalar registers.
+//     (stencil + Threefry), the winner is a DPP max over that quad.
 #pragma once
 #include "rbg_device.h"
 
@@ -43,8 +43,9 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 // Per step ONE Threefry evaluation serves two stages: lanes 0..3 draw the candidates' uniforms
 // with this step's subkey while lanes 4,5 already split the next key (the key chain does not
 // depend on the board; a step that turns out impossible simply does not commit the new key).
-__device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, int N, Key2 key0,
-                                               int lane, int &first_cell, int &last_cell) {
+__device__ __forceinline__ int seq_rw_generate(uint32_t *board, uint32_t *hist, const Geo &g,
+                                               int N, Key2 key0, int lane, int &first_cell,
+                                               int &last_cell) {
   const SubWave<64> sw(lane);
   const int S = g.S, m = g.m;
   const uint32_t n = (uint32_t)g.n;
@@ -65,9 +66,12 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, in
   // took more than L - 1 steps, and there it only stops one step earlier: the state to continue
   // from is the failed attempt's own state with the wires after w* erased and w*'s LAST step
   // undone (its last cell emptied, the cell before it the TARGET again, the key the one it had
-  // before that step's split).  Lane w keeps what that takes for wire w (last two cells, key
-  // before the last step); a wire that has already been cut once cannot be cut again from the
-  // record, and then the attempt replays from the start as the reference does.
+  // before that step's split).  `hist` (when the launch could afford the LDS: N * (2m - 1)
+  // entries of 16 bytes per board) keeps (key, cell) before every committed step of every wire, so
+  // a wire can be cut again and again; without it lane w keeps the record of wire w's last step
+  // only, a wire that has already been cut once cannot be cut again, and then the attempt replays
+  // from the start as the reference does.
+  const int H = 2 * m - 1;  // the longest walk
   int rec_steps = 0, rec_last = 0, rec_prev = 0;
   Key2 rec_key = {0u, 0u};
   bool rec_valid = false;
@@ -128,37 +132,41 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, in
       int steps = 0, prevP = P;
       Key2 key_before = key;  // the key before the last committed step
       for (; steps < limit; ++steps) {
-        // lane d < 4 evaluates candidate d: empty, and touching this wire at most once
-        const int Q = P + dP;
-        const uint32_t vq = board[Q];
-        const uint32_t a = board[Q - S], b = board[Q + S], c = board[Q - 1], d = board[Q + 1];
+        // lane d < 4 evaluates candidate d: empty, and touching this wire at most once (the reads
+        // of the other lanes and of wall candidates stay inside the two wall rows / columns)
+        const uint32_t *q = board + P + dP;
+        const uint32_t vq = q[0], a = q[-S], b = q[S], c = q[-1], d = q[1];
         // one evaluation: candidates' uniforms (subkey of THIS step) + split of the NEXT key
-        const uint2 y = threefry_call(lane < 4 ? step_key.a : key_next.a,
-                                      lane < 4 ? step_key.b : key_next.b, c0, c1);
+        uint32_t y0, y1;
+        threefry(lane < 4 ? step_key.a : key_next.a, lane < 4 ? step_key.b : key_next.b, c0, c1,
+                 y0, y1);
         const int touching = (int)((uint32_t)(a - path) < 3u) + (int)((uint32_t)(b - path) < 3u) +
                              (int)((uint32_t)(c - path) < 3u) + (int)((uint32_t)(d - path) < 3u);
         const bool avail = lane < 4 && vq == 0u && touching <= 1;
-        const uint32_t amask = (uint32_t)__ballot(avail) & 0xFu;
-        if (amask == 0u) break;  // can_step == False now and for every later trip of the loop
-        // one_step: key, subkey = split(key) is committed; choice over the padded candidates
-        key_before = key;
-        key = key_next;
-        key_next.a = __builtin_amdgcn_readlane(y.x, 4);
-        key_next.b = __builtin_amdgcn_readlane(y.x, 5);
-        step_key.a = __builtin_amdgcn_readlane(y.y, 4);
-        step_key.b = __builtin_amdgcn_readlane(y.y, 5);
-        const uint32_t u = (cand_hi ? y.y : y.x) >> 9;
-        int pick = -1;
-        uint32_t pick_u = 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const uint32_t uk = __builtin_amdgcn_readlane(u, k);
-          if (((amask >> k) & 1u) && (pick < 0 || uk > pick_u)) {
-            pick = k;
-            pick_u = uk;
-          }
+        // choice over the padded candidates = the available one with the largest uniform, the
+        // lowest index on ties: a max over quad 0 of (uniform, 3 - index) + 1, 0 = not available
+        const uint32_t u = (cand_hi ? y1 : y0) >> 9;
+        uint32_t score = avail ? ((u << 2) | (3u - (uint32_t)lane)) + 1u : 0u;
+        {
+          const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)score, 0xB1, 0xF, 0xF, false);
+          score = o > score ? o : score;
+          const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)score, 0x4E, 0xF, 0xF, false);
+          score = o2 > score ? o2 : score;
         }
-        const int stepP = pick == 0 ? -S : pick == 1 ? S : pick == 2 ? -1 : 1;
+        const uint32_t best = (uint32_t)__builtin_amdgcn_readfirstlane((int)score);
+        if (best == 0u) break;  // can_step == False now and for every later trip of the loop
+        // one_step: key, subkey = split(key) is committed
+        key_before = key;
+        if (hist != nullptr && lane == 0)
+          *reinterpret_cast<uint4 *>(&hist[(w * H + steps) * 4]) =
+              make_uint4(key.a, key.b, (uint32_t)P, 0u);
+        key = key_next;
+        key_next.a = __builtin_amdgcn_readlane(y0, 4);
+        key_next.b = __builtin_amdgcn_readlane(y0, 5);
+        step_key.a = __builtin_amdgcn_readlane(y1, 4);
+        step_key.b = __builtin_amdgcn_readlane(y1, 5);
+        const int pick = 3 - (int)((best - 1u) & 3u);
+        const int stepP = __builtin_amdgcn_sbfe((int)g.step_table, (uint32_t)pick * 8u, 8u);
         if (lane == 0) {
           board[P + stepP] = tail;  // the new cell is the wire's TARGET ...
           board[P] = path;          // ... the old one becomes PATH
@@ -194,12 +202,24 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, const Geo &g, in
     // the first wire that took s_max steps is the one the next attempt cuts
     const int ws = __builtin_amdgcn_readfirstlane(
         (int)__ffsll((long long)__ballot(lane < w && rec_steps == s_max)) - 1);
-    fresh = ws < 0 || __builtin_amdgcn_readlane((int)rec_valid, ws) == 0;
+    int lastP = 0, prevP = 0;
+    fresh = ws < 0;
     if (!fresh) {
-      const int lastP = __builtin_amdgcn_readlane(rec_last, ws);
-      const int prevP = __builtin_amdgcn_readlane(rec_prev, ws);
-      key.a = (uint32_t)__builtin_amdgcn_readlane((int)rec_key.a, ws);
-      key.b = (uint32_t)__builtin_amdgcn_readlane((int)rec_key.b, ws);
+      lastP = __builtin_amdgcn_readlane(rec_last, ws);
+      if (hist != nullptr) {  // wire ws took s_max steps: the state before its last one
+        const uint4 e = *reinterpret_cast<const uint4 *>(&hist[(ws * H + s_max - 1) * 4]);
+        key.a = __builtin_amdgcn_readfirstlane(e.x);
+        key.b = __builtin_amdgcn_readfirstlane(e.y);
+        prevP = __builtin_amdgcn_readfirstlane((int)e.z);
+      } else if (__builtin_amdgcn_readlane((int)rec_valid, ws) != 0) {
+        prevP = __builtin_amdgcn_readlane(rec_prev, ws);
+        key.a = (uint32_t)__builtin_amdgcn_readlane((int)rec_key.a, ws);
+        key.b = (uint32_t)__builtin_amdgcn_readlane((int)rec_key.b, ws);
+      } else {
+        fresh = true;
+      }
+    }
+    if (!fresh) {
       const uint32_t first_gone = 3u * (uint32_t)(ws + 1) + 1u;  // smallest value of a later wire
       for (int idx = lane; idx < g.n; idx += kWaveSize) {
         const int r = div_m(g, idx);
