@@ -115,6 +115,8 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, uint32_t *hist, 
         }
       }
       best = wave_max_u64(best);
+      best = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(best >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)best);  // uniform, and known to be
       if (best == 0ull) {  // can_start == False
         success = false;
         break;
@@ -136,6 +138,7 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, uint32_t *hist, 
         // of the other lanes and of wall candidates stay inside the two wall rows / columns)
         const uint32_t *q = board + P + dP;
         const uint32_t vq = q[0], a = q[-S], b = q[S], c = q[-1], d = q[1];
+        __builtin_amdgcn_sched_barrier(0);  // all five reads in flight under the Threefry rounds
         // one evaluation: candidates' uniforms (subkey of THIS step) + split of the NEXT key
         uint32_t y0, y1;
         threefry(lane < 4 ? step_key.a : key_next.a, lane < 4 ? step_key.b : key_next.b, c0, c1,
@@ -181,7 +184,7 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, uint32_t *hist, 
         success = false;
         break;
       }
-      s_max = steps > s_max ? steps : s_max;
+      s_max = __builtin_amdgcn_readfirstlane(steps > s_max ? steps : s_max);
       if (lane == w) {
         int r, c;
         unpad_index(g, P0, r, c);
@@ -197,7 +200,7 @@ __device__ __forceinline__ int seq_rw_generate(uint32_t *board, uint32_t *hist, 
     }
     if (success) return attempt;
     // `w` is the wire that failed; the wires before it replay identically while limit >= s_max
-    limit = s_max - 1;  // (s_max <= the old limit)
+    limit = __builtin_amdgcn_readfirstlane(s_max - 1);  // (s_max <= the old limit)
     if (limit < 1) break;  // limit 0 lets no wire move: every remaining attempt fails
     // the first wire that took s_max steps is the one the next attempt cuts
     const int ws = __builtin_amdgcn_readfirstlane(

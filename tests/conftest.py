@@ -39,3 +39,22 @@ def oracle():
 
 def as_np(x, dtype=np.int32):
     return np.asarray(x, dtype=dtype)
+
+
+@pytest.fixture(scope="session")
+def slow_path_lib(tmp_path_factory):
+    """A build of the library (compiled where the test runs) whose rarely taken exact paths are
+    the only ones: no prepared tries past the last cell in SeedExtension (RBG_SE_MARGIN=0), no
+    step history for SequentialRandomWalk retries (RBG_SEQ_HISTORY_BYTES=0)."""
+    import ctypes as C
+    import subprocess
+
+    from routing_board_generation_amd import _native as nat
+
+    so = str(tmp_path_factory.mktemp("variant") / "librbg_slow_paths.so")
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
+                          ["-DRBG_SE_MARGIN=0", "-DRBG_SEQ_HISTORY_BYTES=0", "-o", so, nat.SRC_PATH])
+    lib = C.CDLL(so)
+    for name, (restype, argtypes) in nat.SIGNATURES.items():
+        getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+    return lib

@@ -530,6 +530,28 @@ def test_many_sequential_boards_match_oracle(rbg, oracle, m, N, log2b):
         assert_dicts_equal(got, est, f"seq_rw {m}x{m}/{N}: ")
 
 
+def test_sequential_retries_without_step_history(rbg, oracle, torch_mod, slow_path_lib):
+    """Shapes whose step history does not fit the LDS budget keep one record per wire and replay
+    an attempt from the start when a wire has to be cut twice; a build without any history takes
+    that path on every shape."""
+    torch = torch_mod
+    for (m, N, B, seed) in ((16, 10, 2048, 41), (8, 8, 2048, 42), (6, 5, 1024, 43), (10, 9, 1024, 44)):
+        keys = _keys(rbg, seed, B)
+        i32 = dict(dtype=torch.int32, device="cuda")
+        solved, train = torch.empty((B, m, m), **i32), torch.empty((B, m, m), **i32)
+        start, target = torch.empty((B, N, 2), **i32), torch.empty((B, N, 2), **i32)
+        attempts = torch.empty((B,), **i32)
+        rc = slow_path_lib.rbg_seq_rw_generate(
+            keys.data_ptr(), B, m, N, 1, solved.data_ptr(), train.data_ptr(), start.data_ptr(),
+            target.data_ptr(), None, None, None, attempts.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, slow_path_lib.rbg_last_error()
+        est, esolved, eatt = oracle.seq_rw_generator_batch(to_np(keys), m, N, threads=16)
+        assert (to_np(attempts) == eatt).all() and (eatt > 2).any()
+        assert (to_np(solved) == esolved).all() and (to_np(train) == est["grid"]).all()
+        assert (to_np(start) == est["start"]).all() and (to_np(target) == est["target"]).all()
+
+
 def test_sequential_random_walk_board_api(rbg, oracle):
     board = rbg.SequentialRandomWalkBoard(10, 10, 5)
     keys = _keys(rbg, 9, 16)

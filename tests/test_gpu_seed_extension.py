@@ -269,24 +269,14 @@ def test_shard_invariance_of_the_other_generators(rbg):
                 assert (to_np(part[f]) == to_np(full[f])[lo:hi]).all(), (name, f, lo, hi)
 
 
-def test_seed_extension_tries_beyond_the_prepared_chain(rbg, oracle, tmp_path):
+def test_seed_extension_tries_beyond_the_prepared_chain(rbg, oracle, slow_path_lib):
     """A cell's tries read the direction numbers phase A prepared for chain positions up to
     n + RBG_SE_MARGIN; beyond that a slow exact path recomputes from K_n.  With the default margin
     that path is rare: a build with margin 0 (compiled here, on the GPU box) takes it for every
     try that runs past the last cell, and must still reproduce the oracle bit for bit."""
-    import ctypes as C
-    import subprocess
-
     import torch
 
-    from routing_board_generation_amd import _native as nat
-
-    so = str(tmp_path / "librbg_margin0.so")
-    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
-                          ["-DRBG_SE_MARGIN=0", "-o", so, nat.SRC_PATH])
-    lib = C.CDLL(so)
-    for name, (restype, argtypes) in nat.SIGNATURES.items():
-        getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes
+    lib = slow_path_lib
     for (m, N, B, seed, randomness) in ((8, 16, 512, 31, 1.0), (10, 5, 1024, 32, 0.0),
                                         (5, 4, 256, 33, 0.5)):
         keys = _keys(rbg, seed, B)
