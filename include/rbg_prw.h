@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 5
+#define RBG_ABI_VERSION 6
 
 #define RBG_E_NULL (-1)   /* a required pointer is NULL */
 #define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
@@ -270,6 +270,49 @@ int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream);
  * (legal actions in ascending order; NOOP is always legal). */
 int rbg_random_actions(const uint32_t *keys, int B, int N, uint32_t t, const uint8_t *action_mask,
                        int32_t *action, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The walk taken apart: the methods of ParallelRandomWalkBoard that the reference's unit tests
+ * call one by one (JAXI/board_generation/test_parallel_random_walk_board.py), on grids in the
+ * reference's encoding (PATH 1 + 3i, POSITION 2 + 3i, TARGET 3 + 3i) and with the reference's
+ * treatment of arbitrary arguments (flat cells go through python floor division, -1 = no cell,
+ * out-of-range gathers wrap once and clamp).  generate_board does not go through these: it runs
+ * the fused walk.  Agents are (target, position) [B][N][2]; Agent.id = arange(N).
+ * ------------------------------------------------------------------------------------------- */
+
+/* _initialise_agents(key, grid) (parallel_random_walk.py:147-186): start = the first N entries of
+ * jax.random.permutation(key, m * m); grid_out = grid_in (NULL = empty) with the heads 2 + 3i
+ * max-joined over the agents' private copies.  start doubles as Agent.position; target = -1. */
+int rbg_prw_initialise_agents(const uint32_t *keys, int B, int m, int N, const int32_t *grid_in,
+                              int32_t *grid_out, int32_t *start, void *stream);
+
+/* _step((key, grid, agents)) (:92-145): one iteration of the walk.  key_out = split(key)[1];
+ * action_out (nullable) = what _select_action drew for every agent.  target NULL = all -1. */
+int rbg_prw_step(const uint32_t *keys, int B, int m, int N, const int32_t *grid,
+                 const int32_t *target, const int32_t *position, uint32_t *key_out,
+                 int32_t *grid_out, int32_t *position_out, int32_t *action_out, void *stream);
+
+/* _select_action(key, grid, agent) (:205-230), one key per agent: agent_keys [B][N][2]. */
+int rbg_prw_select_action(const uint32_t *agent_keys, int B, int m, int N, const int32_t *grid,
+                          const int32_t *position, int32_t *action, void *stream);
+
+/* Q flat cells per board, cells [B][Q] (any int32).  Outputs, all nullable:
+ *   adjacent [B][Q][4]       _adjacent_cells(cell) (:262-291), [up, down, left, right], -1 = none
+ *   available [B][Q][4]      _available_cells(grid, cell) (:293-319)
+ *   is_free [B][Q]           _is_cell_free(grid, cell)[1] (:321-338)
+ *   not_doubling_back [B][Q] _is_cell_doubling_back((grid, wire), cell)[1] (:340-374) with
+ *                            wire = wire_id[b][q], or (grid[cell] - 1) // 3 when wire_id is NULL
+ * grid may be NULL when only `adjacent` is asked for. */
+int rbg_prw_cell_queries(const int32_t *grid, int B, int m, const int32_t *cells, int Q,
+                         const int32_t *wire_id, int32_t *adjacent, int32_t *available,
+                         uint8_t *is_free, uint8_t *not_doubling_back, void *stream);
+
+/* _step_agent(agent, grid, action) (:376-429) for every agent on its OWN copy of the grid:
+ * new_position [B][N][2]; new_grids [B][N][m][m] (nullable); moved [B][N] (nullable) =
+ * _is_valid_position(grid, agent, move_position(position, action)) & (action != NOOP). */
+int rbg_prw_step_agent(const int32_t *grid, int B, int m, int N, const int32_t *target,
+                       const int32_t *position, const int32_t *action, int32_t *new_position,
+                       int32_t *new_grids, uint8_t *moved, void *stream);
 
 /* Per-env counters of a rollout (all members nullable, each int32 [B], overwritten per call).
  * Returns are integer counts so that they do not depend on a summation order:

@@ -156,9 +156,23 @@ def step_agent(agent_i, agents, grid, action):
     return ([new_agent.position[0], new_agent.position[1]], new_grid)
 
 
-def initialise_agents(key, m, N):
+def not_doubling_back(grid, wire_id, cell):
+    grid = _i32(grid)
+    return bool(lib().oracle_is_cell_not_doubling_back(_p(grid), grid.shape[0], grid.shape[1],
+                                                       int(wire_id), int(cell)))
+
+
+def select_action(key, grid, agents, i):
+    """ParallelRandomWalkBoard._select_action(key, grid, agents[i])."""
     key = _u32(key)
-    grid = np.zeros((m, m), np.int32)
+    grid = _i32(grid)
+    arr = _agents_to_c(agents)
+    return int(lib().oracle_select_action(_p(key), _p(grid), grid.shape[0], C.byref(arr[i])))
+
+
+def initialise_agents(key, m, N, grid=None):
+    key = _u32(key)
+    grid = np.zeros((m, m), np.int32) if grid is None else _i32(grid).copy()
     arr = (AgentT * N)()
     lib().oracle_initialise_agents(_p(key), _p(grid), arr, m, N)
     return grid, _agents_from_c(arr)

@@ -313,6 +313,11 @@ static int is_cell_not_doubling_back(const int32_t *grid, int rows, int cols, in
   return count <= 1;
 }
 
+int oracle_is_cell_not_doubling_back(const int32_t *grid, int rows, int cols, int32_t wire_id,
+                                     int32_t cell) {
+  return is_cell_not_doubling_back(grid, rows, cols, wire_id, cell);
+}
+
 /* :293-319 */
 void oracle_available_cells(const int32_t *grid, int rows, int cols, int32_t cell,
                             int32_t out[4]) {

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
 HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
                "-std=c++17"]
 
@@ -103,6 +103,13 @@ SIGNATURES = {
                                                  C.POINTER(Stash), C.c_int, C.c_int, C.c_void_p]),
     "rbg_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "rbg_prw_initialise_agents": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] +
+                                  [C.c_void_p] * 4),
+    "rbg_prw_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8),
+    "rbg_prw_select_action": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "rbg_prw_cell_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int] +
+                             [C.c_void_p] * 6),
+    "rbg_prw_step_agent": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7),
 }
 
 

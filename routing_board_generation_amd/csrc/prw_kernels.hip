@@ -32,6 +32,7 @@
 #include "rbg_seqwalk.h"
 #include "rbg_seedext.h"
 #include "rbg_walk_philox.h"
+#include "rbg_pieces.h"
 
 namespace {
 
@@ -860,6 +861,178 @@ __global__ void random_actions_kernel(const uint32_t *__restrict__ keys, int B, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The walk taken apart (rbg_pieces.h): the methods of ParallelRandomWalkBoard that the reference's
+// unit tests call one by one.  Not on the hot path; one wave per board or one thread per query.
+// ---------------------------------------------------------------------------------------------
+struct PiecesArgs {
+  const uint32_t *keys;
+  int B, N;
+  Geo g;
+  const int32_t *grid_in;
+  const int32_t *target;
+  const int32_t *position;
+  uint32_t *key_out;
+  int32_t *grid_out;
+  int32_t *position_out;
+  int32_t *action_out;
+};
+
+// _initialise_agents(key, grid) (:147-186): start cells = first N of permutation(key, m * m);
+// every agent sets its head on a private copy of `grid`, the copies are max-joined
+__global__ __launch_bounds__(kBlock) void prw_initialise_agents_kernel(PiecesArgs a) {
+  const int lane = threadIdx.x & (kWaveSize - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * kWavesPerBlock + wib;
+  if (b >= a.B) return;
+  const SubWave<64> sw(lane);
+  const Geo g = a.g;
+  uint32_t *board = g_lds + wib * slab_words<64>(g);
+  uint32_t *W = board + board_words(g);
+  Key2 key = {a.keys[2 * (size_t)b], a.keys[2 * (size_t)b + 1]}, unused, sub;
+  split2_lanes(sw, key, unused, sub);  // _shuffle: key, subkey = split(key)
+  int sel0, sel1;
+  shuffle_prefix(sw, board, W, g, sub, a.N, g.thr, sel0, sel1);
+  if (a.grid_in) load_grid(sw, board, g, a.grid_in + (size_t)b * g.n);
+  else board_clear<64>(board, g, lane);
+  if (lane < a.N) {
+    const int r = div_m(g, sel0), c = sel0 - r * g.m;
+    const uint32_t head = 3u * (uint32_t)lane + 2u;
+    uint32_t *cell = &board[pad_index(g, r, c)];
+    // the other agents' copies still hold the old value: it survives the max when it is larger
+    *cell = (a.N > 1 && (int)*cell > (int)head) ? *cell : head;
+    *reinterpret_cast<int2 *>(&a.position_out[((size_t)b * a.N + lane) * 2]) = make_int2(r, c);
+  }
+  wave_lds_fence();
+  store_grid<64, false>(board, g, lane, a.grid_out + (size_t)b * g.n);
+}
+
+// _step((key, grid, agents)) (:92-145): keys = split(key, N); actions by _select_action; every
+// agent steps on a private grid, the grids are max-joined, colliding agents with the lower id
+// stay (env_step_core is that rule for given actions); next_key = split(key)[1]
+__global__ __launch_bounds__(kBlock) void prw_step_kernel(PiecesArgs a) {
+  const int lane = threadIdx.x & (kWaveSize - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * kWavesPerBlock + wib;
+  if (b >= a.B) return;
+  const SubWave<64> sw(lane);
+  const Geo g = a.g;
+  uint32_t *board = g_lds + wib * slab_words<64>(g);
+  const int m = g.m;
+  AgentRegs ag = {0, 0, -1, -1, 0, 0};
+  if (lane < a.N) {
+    const size_t o = ((size_t)b * a.N + lane) * 2;
+    const int2 p = *reinterpret_cast<const int2 *>(&a.position[o]);
+    ag.r = p.x < 0 ? 0 : p.x >= m ? m - 1 : p.x;
+    ag.c = p.y < 0 ? 0 : p.y >= m ? m - 1 : p.y;
+    if (a.target) {
+      const int2 t = *reinterpret_cast<const int2 *>(&a.target[o]);
+      ag.tr = t.x;
+      ag.tc = t.y;
+    }
+  }
+  load_grid(sw, board, g, a.grid_in + (size_t)b * g.n);
+  const Key2 key = {a.keys[2 * (size_t)b], a.keys[2 * (size_t)b + 1]};
+  int act = 0;
+  if (lane < a.N) {
+    const LdsGrid grid = {board, g.S};
+    act = ref_select_action(split_child(key, (uint32_t)lane, (uint32_t)a.N), grid, m,
+                            ag.r * m + ag.c);
+    if (a.action_out) a.action_out[(size_t)b * a.N + lane] = act;
+  }
+  int step_count = 0;
+  env_step_core<64>(sw, board, g, a.N, ag, step_count, act, 0x7FFFFFFF);
+  store_grid<64, false>(board, g, lane, a.grid_out + (size_t)b * g.n);
+  if (lane < a.N)
+    *reinterpret_cast<int2 *>(&a.position_out[((size_t)b * a.N + lane) * 2]) = make_int2(ag.r, ag.c);
+  Key2 k0, k1;
+  split2_lanes(sw, key, k0, k1);
+  if (lane == 0 && a.key_out)
+    *reinterpret_cast<uint2 *>(&a.key_out[2 * (size_t)b]) = make_uint2(k1.a, k1.b);
+}
+
+// _select_action(key, grid, agent) for every agent of every board, one key per agent
+__global__ void prw_select_action_kernel(const uint32_t *__restrict__ agent_keys, int B, int m,
+                                         int N, const int32_t *__restrict__ grid,
+                                         const int32_t *__restrict__ position,
+                                         int32_t *__restrict__ action) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * N) return;
+  const size_t b = idx / N;
+  const HbmGrid g = {grid + b * (size_t)(m * m), m};
+  const Key2 key = {agent_keys[2 * idx], agent_keys[2 * idx + 1]};
+  action[idx] = ref_select_action(key, g, m, position[2 * idx] * m + position[2 * idx + 1]);
+}
+
+// _adjacent_cells / _available_cells / _is_cell_free / _is_cell_doubling_back of Q cells per board
+__global__ void prw_cell_query_kernel(const int32_t *__restrict__ grid, int B, int m,
+                                      const int32_t *__restrict__ cells, int Q,
+                                      const int32_t *__restrict__ wire_id,
+                                      int32_t *__restrict__ adjacent,
+                                      int32_t *__restrict__ available,
+                                      uint8_t *__restrict__ is_free,
+                                      uint8_t *__restrict__ not_doubling_back) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * Q) return;
+  const int cell = cells[idx];
+  int out[4];
+  if (adjacent) {
+    ref_adjacent_cells(cell, m, out);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) adjacent[idx * 4 + k] = out[k];
+  }
+  if (!grid) return;
+  const HbmGrid g = {grid + (idx / Q) * (size_t)(m * m), m};
+  if (available) {
+    ref_available_cells(g, m, cell, out);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) available[idx * 4 + k] = out[k];
+  }
+  if (is_free) is_free[idx] = (uint8_t)ref_is_cell_free(g, m, cell);
+  if (not_doubling_back) {
+    const int wire = wire_id ? wire_id[idx] : floor_div(ref_gather(g, m, cell) - 1, 3);
+    not_doubling_back[idx] = (uint8_t)ref_not_doubling_back(g, m, wire, cell);
+  }
+}
+
+// _step_agent(agent, grid, action) (:376-429) for every agent on its own copy of the grid
+__global__ void prw_step_agent_kernel(const int32_t *__restrict__ grid, int B, int m, int N,
+                                      const int32_t *__restrict__ target,
+                                      const int32_t *__restrict__ position,
+                                      const int32_t *__restrict__ action,
+                                      int32_t *__restrict__ new_position,
+                                      int32_t *__restrict__ new_grids,
+                                      uint8_t *__restrict__ moved) {
+  const size_t idx = blockIdx.x;  // (board, agent)
+  const size_t b = idx / N;
+  const int i = (int)(idx - b * N), n = m * m;
+  const int32_t *g = grid + b * (size_t)n;
+  const int r = position[2 * idx], c = position[2 * idx + 1];
+  int act = action[idx];
+  act = act < 0 ? 0 : act > 4 ? 4 : act;  // lax.switch clamps its index (move_position)
+  const int nr = r + (act == 1 ? -1 : act == 3 ? 1 : 0), nc = c + (act == 2 ? 1 : act == 4 ? -1 : 0);
+  const bool connected = target && r == target[2 * idx] && c == target[2 * idx + 1];
+  const bool in_bounds = 0 <= nr && nr < m && 0 <= nc && nc < m;
+  bool ok = false;
+  if (in_bounds) {
+    const int v = g[nr * m + nc];
+    ok = (v == 0 || v == 3 * i + 3) && !connected && act != 0;
+  }
+  if (threadIdx.x == 0) {
+    new_position[2 * idx] = ok ? nr : r;
+    new_position[2 * idx + 1] = ok ? nc : c;
+    if (moved) moved[idx] = (uint8_t)ok;
+  }
+  if (!new_grids) return;
+  int32_t *out = new_grids + idx * (size_t)n;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    int v = g[k];
+    if (ok && k == nr * m + nc) v = 3 * i + 2;     // move_agent: the new cell is the head ...
+    else if (ok && k == r * m + c) v = 3 * i + 1;  // ... the old one a path cell
+    out[k] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
 thread_local char g_err[256] = "";
@@ -1385,6 +1558,84 @@ int rbg_random_actions(const uint32_t *keys, int B, int N, uint32_t t, const uin
   hipLaunchKernelGGL(random_actions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, keys, B, N, t, action_mask, action);
   return check_hip(hipGetLastError(), "rbg_random_actions");
+}
+
+int rbg_prw_initialise_agents(const uint32_t *keys, int B, int m, int N, const int32_t *grid_in,
+                              int32_t *grid_out, int32_t *start, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_prw_initialise_agents: B < 0");
+  PiecesArgs a = {};
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (B == 0) return 0;
+  if (!keys || !grid_out || !start) return fail(RBG_E_NULL, "rbg_prw_initialise_agents: NULL pointer");
+  if (int rc = check_align(a.g, grid_in, grid_out, nullptr)) return rc;
+  a.keys = keys; a.B = B; a.N = N; a.grid_in = grid_in; a.grid_out = grid_out; a.position_out = start;
+  hipLaunchKernelGGL(prw_initialise_agents_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
+                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  return check_hip(hipGetLastError(), "rbg_prw_initialise_agents");
+}
+
+int rbg_prw_step(const uint32_t *keys, int B, int m, int N, const int32_t *grid,
+                 const int32_t *target, const int32_t *position, uint32_t *key_out,
+                 int32_t *grid_out, int32_t *position_out, int32_t *action_out, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_prw_step: B < 0");
+  PiecesArgs a = {};
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  if (B == 0) return 0;
+  if (!keys || !grid || !position || !grid_out || !position_out)
+    return fail(RBG_E_NULL, "rbg_prw_step: NULL pointer");
+  if (int rc = check_align(a.g, grid, grid_out, nullptr)) return rc;
+  a.keys = keys; a.B = B; a.N = N; a.grid_in = grid; a.target = target; a.position = position;
+  a.key_out = key_out; a.grid_out = grid_out; a.position_out = position_out; a.action_out = action_out;
+  hipLaunchKernelGGL(prw_step_kernel, dim3((B + kWavesPerBlock - 1) / kWavesPerBlock),
+                     dim3(kBlock), lds_bytes(a.g), (hipStream_t)stream, a);
+  return check_hip(hipGetLastError(), "rbg_prw_step");
+}
+
+int rbg_prw_select_action(const uint32_t *agent_keys, int B, int m, int N, const int32_t *grid,
+                          const int32_t *position, int32_t *action, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_prw_select_action: B < 0");
+  Geo g;
+  if (int rc = make_geo(m, N, &g)) return rc;
+  const size_t total = (size_t)B * (size_t)N;
+  if (total == 0) return 0;
+  if (!agent_keys || !grid || !position || !action)
+    return fail(RBG_E_NULL, "rbg_prw_select_action: NULL pointer");
+  hipLaunchKernelGGL(prw_select_action_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, agent_keys, B, m, N, grid, position, action);
+  return check_hip(hipGetLastError(), "rbg_prw_select_action");
+}
+
+int rbg_prw_cell_queries(const int32_t *grid, int B, int m, const int32_t *cells, int Q,
+                         const int32_t *wire_id, int32_t *adjacent, int32_t *available,
+                         uint8_t *is_free, uint8_t *not_doubling_back, void *stream) {
+  if (B < 0 || Q < 0) return fail(RBG_E_SHAPE, "rbg_prw_cell_queries: negative size");
+  if (m < 2 || m > kMaxM) return fail(RBG_E_SHAPE, "grid size m must be in [2, 40]");
+  const size_t total = (size_t)B * (size_t)Q;
+  if (total == 0) return 0;
+  if (!cells) return fail(RBG_E_NULL, "rbg_prw_cell_queries: cells is NULL");
+  if (!grid && (available || is_free || not_doubling_back))
+    return fail(RBG_E_NULL, "rbg_prw_cell_queries: these outputs need a grid");
+  hipLaunchKernelGGL(prw_cell_query_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, grid, B, m, cells, Q, wire_id, adjacent, available,
+                     is_free, not_doubling_back);
+  return check_hip(hipGetLastError(), "rbg_prw_cell_queries");
+}
+
+int rbg_prw_step_agent(const int32_t *grid, int B, int m, int N, const int32_t *target,
+                       const int32_t *position, const int32_t *action, int32_t *new_position,
+                       int32_t *new_grids, uint8_t *moved, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_prw_step_agent: B < 0");
+  Geo g;
+  if (int rc = make_geo(m, N, &g)) return rc;
+  const size_t total = (size_t)B * (size_t)N;
+  if (total == 0) return 0;
+  if (total > 0x7FFFFFFFull) return fail(RBG_E_SHAPE, "rbg_prw_step_agent: B * N too large");
+  if (!grid || !position || !action || !new_position)
+    return fail(RBG_E_NULL, "rbg_prw_step_agent: NULL pointer");
+  hipLaunchKernelGGL(prw_step_agent_kernel, dim3((unsigned)total), dim3(256), 0,
+                     (hipStream_t)stream, grid, B, m, N, target, position, action, new_position,
+                     new_grids, moved);
+  return check_hip(hipGetLastError(), "rbg_prw_step_agent");
 }
 
 }  // extern "C"

@@ -316,6 +316,108 @@ def dataset_sample(keys: torch.Tensor, heads: torch.Tensor, targets: torch.Tenso
     return st, which
 
 
+# --------------------------------------------------------------------- the walk taken apart
+def prw_initialise_agents(keys: torch.Tensor, m: int, N: int,
+                          grid: Optional[torch.Tensor] = None):
+    """_initialise_agents for keys [B, 2] (grid [B, m, m] int32 or None = empty)
+    -> (grid [B, m, m], start [B, N, 2])."""
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    if grid is not None:
+        _check(grid, torch.int32, (B, m, m), "grid")
+    out = torch.empty((B, m, m), dtype=torch.int32, device=dev)
+    start = torch.empty((B, N, 2), dtype=torch.int32, device=dev)
+    nat.check(nat.lib().rbg_prw_initialise_agents(keys.data_ptr(), B, m, N, _ptr(grid),
+                                                  out.data_ptr(), start.data_ptr(), _stream(dev)),
+              "rbg_prw_initialise_agents")
+    return out, start
+
+
+def prw_step(keys: torch.Tensor, grid: torch.Tensor, target: Optional[torch.Tensor],
+             position: torch.Tensor, want_actions: bool = False):
+    """_step for B boards -> (next keys [B, 2], grid [B, m, m], position [B, N, 2], actions)."""
+    keys = check_keys(keys)
+    B, dev = keys.shape[0], keys.device
+    m, N = grid.shape[-1], position.shape[1]
+    _check(grid, torch.int32, (B, m, m), "grid")
+    _check(position, torch.int32, (B, N, 2), "position")
+    if target is not None:
+        _check(target, torch.int32, (B, N, 2), "target")
+    key_out = torch.empty_like(keys)
+    grid_out, pos_out = torch.empty_like(grid), torch.empty_like(position)
+    actions = torch.empty((B, N), dtype=torch.int32, device=dev) if want_actions else None
+    nat.check(nat.lib().rbg_prw_step(keys.data_ptr(), B, m, N, grid.data_ptr(), _ptr(target),
+                                     position.data_ptr(), key_out.data_ptr(), grid_out.data_ptr(),
+                                     pos_out.data_ptr(), _ptr(actions), _stream(dev)),
+              "rbg_prw_step")
+    return key_out, grid_out, pos_out, actions
+
+
+def prw_select_action(agent_keys: torch.Tensor, grid: torch.Tensor,
+                      position: torch.Tensor) -> torch.Tensor:
+    """_select_action with one key per agent: agent_keys [B, N, 2] -> actions [B, N]."""
+    B, N = position.shape[0], position.shape[1]
+    m, dev = grid.shape[-1], grid.device
+    _check(agent_keys, torch.uint32, (B, N, 2), "agent_keys")
+    _check(grid, torch.int32, (B, m, m), "grid")
+    _check(position, torch.int32, (B, N, 2), "position")
+    action = torch.empty((B, N), dtype=torch.int32, device=dev)
+    nat.check(nat.lib().rbg_prw_select_action(agent_keys.data_ptr(), B, m, N, grid.data_ptr(),
+                                              position.data_ptr(), action.data_ptr(),
+                                              _stream(dev)), "rbg_prw_select_action")
+    return action
+
+
+def prw_cell_queries(grid: Optional[torch.Tensor], cells: torch.Tensor, m: int,
+                     wire_id: Optional[torch.Tensor] = None, want=("adjacent",)) -> dict:
+    """cells [B, Q] int32 -> the requested of adjacent / available [B, Q, 4] int32, is_free /
+    not_doubling_back [B, Q] bool."""
+    B, Q = cells.shape
+    dev = cells.device
+    _check(cells, torch.int32, (B, Q), "cells")
+    if grid is not None:
+        _check(grid, torch.int32, (B, m, m), "grid")
+    if wire_id is not None:
+        _check(wire_id, torch.int32, (B, Q), "wire_id")
+    out = {}
+    for name in want:
+        if name in ("adjacent", "available"):
+            out[name] = torch.empty((B, Q, 4), dtype=torch.int32, device=dev)
+        elif name in ("is_free", "not_doubling_back"):
+            out[name] = torch.empty((B, Q), dtype=torch.uint8, device=dev)
+        else:
+            raise ValueError(f"unknown cell query {name!r}")
+    nat.check(nat.lib().rbg_prw_cell_queries(
+        _ptr(grid), B, m, cells.data_ptr(), Q, _ptr(wire_id), _ptr(out.get("adjacent")),
+        _ptr(out.get("available")), _ptr(out.get("is_free")), _ptr(out.get("not_doubling_back")),
+        _stream(dev)), "rbg_prw_cell_queries")
+    for name in ("is_free", "not_doubling_back"):
+        if name in out:
+            out[name] = out[name].bool()
+    return out
+
+
+def prw_step_agent(grid: torch.Tensor, target: Optional[torch.Tensor], position: torch.Tensor,
+                   action: torch.Tensor, want_grids: bool = True):
+    """_step_agent of every agent on its own copy of the grid -> (new position [B, N, 2],
+    grids [B, N, m, m] or None, moved [B, N] bool)."""
+    B, N = position.shape[0], position.shape[1]
+    m, dev = grid.shape[-1], grid.device
+    _check(grid, torch.int32, (B, m, m), "grid")
+    _check(position, torch.int32, (B, N, 2), "position")
+    _check(action, torch.int32, (B, N), "action")
+    if target is not None:
+        _check(target, torch.int32, (B, N, 2), "target")
+    new_pos = torch.empty_like(position)
+    grids = torch.empty((B, N, m, m), dtype=torch.int32, device=dev) if want_grids else None
+    moved = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    nat.check(nat.lib().rbg_prw_step_agent(grid.data_ptr(), B, m, N, _ptr(target),
+                                           position.data_ptr(), action.data_ptr(),
+                                           new_pos.data_ptr(), _ptr(grids), moved.data_ptr(),
+                                           _stream(dev)), "rbg_prw_step_agent")
+    return new_pos, grids, moved.bool()
+
+
 # ------------------------------------------------------------------------------------- Connector
 def connector_reset(keys: torch.Tensor, m: int, N: int, state: Optional[StateBufs] = None,
                     timestep: Optional[TimestepBufs] = None):
