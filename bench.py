@@ -323,7 +323,9 @@ def all_configs():
     from routing_board_generation_amd import ops
 
     threads = host_cpu_share()
-    rows = []
+    rows = [{"note": "HIP-event time per call of the allocating Python op (fresh output tensors "
+                     "every call, 20-50 calls after warm-up): a few microseconds above the "
+                     "pre-bound launches of the default line, and host-bound for the tiny configs"}]
 
     def gen_row(name, m, N, B, kind="prw"):
         keys = rbg.split(rbg.PRNGKey(0), B)
