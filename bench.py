@@ -57,17 +57,27 @@ def env_step_bytes(m: int, N: int) -> int:
     return read + write
 
 
-def measured_traffic(kernel: str, boards: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
-    written by tools/summarize_profile.py; counters cannot be read from inside this process).
-    Only valid for the launch shape it was measured on (B = 4096, 16x16/10)."""
-    import glob
+def committed_profile(kind: str, population: str = ""):
+    """The newest round's profiles/rNN<population>_<kind>.json (tools/summarize_profile.py).
+    population: "" = the default run, "_step" = --mode step-replay, "_stream" = --mode stream."""
+    import re
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))  # rNN tags
-    if not files or boards != BATCH_PER_GPU:
+    best = None
+    for f in os.listdir(os.path.join(ROOT, "profiles")):
+        mt = re.fullmatch(r"r(\d+)([a-z]*)" + re.escape(population) + "_" + kind + r"\.json", f)
+        if mt and (best is None or (int(mt.group(1)), mt.group(2)) > best[0]):
+            best = ((int(mt.group(1)), mt.group(2)), f)
+    return json.load(open(os.path.join(ROOT, "profiles", best[1]))) if best else None
+
+
+def measured_traffic(kernel: str, boards: int, population: str = "", shape_boards: int = None):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (counters cannot be read from
+    inside this process).  Only valid for the launch shape that run measured: B = 4096 for the
+    default and "_step" runs, the stream batch for "_stream"."""
+    prof = committed_profile("hbm_traffic", population)
+    if prof is None or boards != (BATCH_PER_GPU if shape_boards is None else shape_boards):
         return None
-    kernels = json.load(open(files[-1]))["kernels"]
-    for name, rec in kernels.items():  # template instances are listed as name<...>
+    for name, rec in prof["kernels"].items():  # template instances are listed as name<...>
         if name == kernel or name.startswith(kernel + "<"):
             return rec["hbm_bytes_per_launch"]
     return None
@@ -99,12 +109,10 @@ def host_cpu_model() -> str:
 def measured_issue(kernel: str, boards: int):
     """VALU wave-instructions per launch from the committed SQ counter pass
     (profiles/*_issue.json, tools/summarize_profile.py); B = 4096, 16x16/10 only."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue.json")))
-    if not files or boards != BATCH_PER_GPU:
+    prof = committed_profile("issue")
+    if prof is None or boards != BATCH_PER_GPU:
         return None
-    for name, rec in json.load(open(files[-1]))["kernels"].items():
+    for name, rec in prof["kernels"].items():
         if name == kernel or name.startswith(kernel + "<"):
             return rec
     return None
@@ -420,6 +428,7 @@ def pure_stream(rbg, ops, torch, dev, m, N, sb, Bs, copy_gbs=None):
             "peak_measured_copy": copy_gbs, "frac_of_measured_copy": p_ach / copy_gbs,
             **({"peak_measured": peaks} if peaks else {}),
             "algorithmic_bytes_per_launch": Bs * sb,
+            "traffic": measured_traffic("connector_step_kernel", Bs, "_stream", 65536),
             "note": "connector_step_kernel, NOOP actions (no terminations), working set "
                     f"{Bs * sb / 1e6:.0f} MB > 256 MiB Infinity Cache; 92 % of its bytes are "
                     "write-once non-temporal stores, which is why it can exceed the measured "
@@ -784,7 +793,7 @@ def main() -> None:
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                  "peak_measured_copy": copy_gbs,
                                  "frac_of_measured_copy": ach / copy_gbs if copy_gbs else None,
-                                 "traffic": measured_traffic("connector_step_kernel", B),
+                                 "traffic": measured_traffic("connector_step_kernel", B, "_step"),
                                  "algorithmic_bytes_per_launch": B * sb,
                                  "bytes_per_env_step": sb, "kernel_avg_ms": k_step,
                                  "span_with_refills_ms": k_span,
