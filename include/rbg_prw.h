@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 6
+#define RBG_ABI_VERSION 7
 
 #define RBG_E_NULL (-1)   /* a required pointer is NULL */
 #define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
@@ -351,6 +351,24 @@ int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_i
                                    const rbg_rollout_stats *stats,
                                    const rbg_timestep *last_timestep, const rbg_stash *stash,
                                    int tick, int ready_delay, void *stream);
+
+/* The same rollout that also RECORDS the trajectory an acting loop collects
+ * (benchmarking/benchmarks/benchmark_on_random_agent.py:71-86, the lax.scan over env.step inside
+ * run_epoch): `trajectory` is an rbg_timestep whose arrays have a leading n_steps axis -- member
+ * x of step s and env b at row s * B + b -- and receives, for every step, exactly what
+ * rbg_connector_step would have returned for it (observation of the next episode after an
+ * auto-reset, reward / discount / step_type / extras of the step that ended); trajectory_action
+ * (int32 [n_steps][B][N], nullable) receives the policy's actions.  All members nullable.  With
+ * the observation recorded the launch is an HBM stream (11.7 KB per env-step at 16x16/10) whose
+ * launch cost is paid once per n_steps.  stash may be NULL. */
+int rbg_connector_rollout_record(int B, int m, int N, const rbg_state *state_in,
+                                 const rbg_state *state_out, const uint32_t *policy_keys,
+                                 uint32_t t0, int n_steps, const rbg_env_params *params,
+                                 const rbg_rollout_stats *stats,
+                                 const rbg_timestep *last_timestep,
+                                 const rbg_timestep *trajectory, int32_t *trajectory_action,
+                                 const rbg_stash *stash, int tick, int ready_delay,
+                                 void *stream);
 
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
 HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
                "-std=c++17"]
 
@@ -101,6 +101,12 @@ SIGNATURES = {
                                                  C.c_int, C.POINTER(EnvParams),
                                                  C.POINTER(RolloutStats), C.POINTER(Timestep),
                                                  C.POINTER(Stash), C.c_int, C.c_int, C.c_void_p]),
+    "rbg_connector_rollout_record": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(State),
+                                               C.POINTER(State), C.c_void_p, C.c_uint32, C.c_int,
+                                               C.POINTER(EnvParams), C.POINTER(RolloutStats),
+                                               C.POINTER(Timestep), C.POINTER(Timestep),
+                                               C.c_void_p, C.POINTER(Stash), C.c_int, C.c_int,
+                                               C.c_void_p]),
     "rbg_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "rbg_prw_initialise_agents": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] +

@@ -193,11 +193,14 @@ class Connector:
 
     # ---------------------------------------------------------------------------------- rollout
     def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,
-                       want_timestep: bool = False):
+                       want_timestep: bool = False, record: bool = False):
         """n_steps of `step` under the masked-uniform random policy (ops.random_actions) in ONE
         kernel launch: the rollout loop of benchmark_on_random_agent.py:59-102 with jumanji's
         RandomAgent.  Batched states only.  Returns (state, stats, timestep-of-the-last-step or
-        None); stats are per-env int32 counters (include/rbg_prw.h::rbg_rollout_stats)."""
+        None); stats are per-env int32 counters (include/rbg_prw.h::rbg_rollout_stats).
+        record=True returns (state, actions [n_steps, B, N], TimeStep with a leading time axis)
+        instead: the trajectory the acting loop collects -- entry s is what the s-th
+        `step(state, action)` of the loop returns (what `lax.scan` stacks in run_epoch)."""
         if state.grid.dim() != 3:
             raise ValueError("random_rollout expects a batched state")
         if self._auto_reset and not isinstance(self._generator, ParallelRandomWalkGenerator):
@@ -212,6 +215,12 @@ class Connector:
                 self._rollout_epochs.clear()
                 epochs = self._rollout_epochs[(B, dev)] = ops.EpochStash(
                     B, self.grid_size, self.num_agents, dev, every=1, serial=True, depth=2)
+        if record:
+            so, _, traj = ops.connector_rollout_record(
+                _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
+                self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
+                auto_reset=self._auto_reset, epochs=epochs)
+            return _make_state(so, True), traj["action"], _make_timestep(traj, True)
         so, stats, ts = ops.connector_rollout(
             _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
             self._reward_fn.timestep_reward, self._reward_fn.connected_reward,

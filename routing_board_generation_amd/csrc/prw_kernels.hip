@@ -667,6 +667,8 @@ struct RolloutArgs {
   TimestepPtrs ts;  // timestep of the LAST step of the rollout (all members nullable)
   StashPtrs stash;  // optional next-episode stash
   int tick, ready_delay;
+  TimestepPtrs traj;     // kRecord: every step's timestep, arrays [n_steps][B]... (members nullable)
+  int32_t *traj_action;  // kRecord: the actions taken, [n_steps][B][N] (nullable)
 };
 
 // One env per sub-wave of LPB lanes (the host picks the smallest LPB that holds the walk's 2N + 2
@@ -695,8 +697,13 @@ __device__ __forceinline__ Key2 uni(Key2 k) {
   }
   return k;
 }
-template <int LPB>
-__global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? RBG_ROLLOUT64_WAVES : 2)) void connector_rollout_kernel(
+// kRecord: the launch also writes the timestep of EVERY step (the trajectory an acting loop
+// collects: observation, mask, reward, discount, step_type, extras, action) -- n_steps x 11.7 KB
+// per env at 16x16/10, which makes it an HBM stream instead of an LDS-resident loop.
+// (a recording full-wave env needs a few registers more than the 128 of four waves per SIMD
+// leave; it is HBM-bound, so three waves per SIMD cost it nothing)
+template <int LPB, bool kRecord>
+__global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLLOUT64_WAVES) : 2)) void connector_rollout_kernel(
     RolloutArgs a) {
   constexpr int kSubs = SubWave<LPB>::kSubs;
   const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
@@ -743,6 +750,12 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? RBG_ROLLOUT64_WAVES : 2
       write_step_outcome(sw, res, a.p, N, b, a.ts);
       write_extras(sw, board, g, N, b, ag, a.ts);
     }
+    const int row = s * a.B + b;  // of the trajectory arrays
+    if constexpr (kRecord) {
+      if (a.traj_action && is_agent) a.traj_action[(size_t)row * N + l] = act;
+      write_step_outcome(sw, res, a.p, N, row, a.traj);
+      write_extras(sw, board, g, N, row, ag, a.traj);  // of the terminal state when it is one
+    }
     if (res.last) {  // per env
       episodes = uni<LPB>(episodes + 1);
       fin_conn = uni<LPB>(fin_conn + __popcll(sw.ballot(res.connected)));
@@ -764,6 +777,8 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? RBG_ROLLOUT64_WAVES : 2
         bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
       }
     }
+    // (after an auto-reset: the observation of the episode that starts, like the wrapper's)
+    if constexpr (kRecord) write_observation(sw, board, g, N, row, ag, step_count, a.traj, bits);
   }
   store_state(sw, board, g, N, b, ag, step_count, key, a.out);
   write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
@@ -1471,6 +1486,19 @@ int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_i
                                    const rbg_rollout_stats *stats,
                                    const rbg_timestep *last_timestep, const rbg_stash *stash,
                                    int tick, int ready_delay, void *stream) {
+  return rbg_connector_rollout_record(B, m, N, state_in, state_out, policy_keys, t0, n_steps,
+                                      params, stats, last_timestep, nullptr, nullptr, stash, tick,
+                                      ready_delay, stream);
+}
+
+int rbg_connector_rollout_record(int B, int m, int N, const rbg_state *state_in,
+                                 const rbg_state *state_out, const uint32_t *policy_keys,
+                                 uint32_t t0, int n_steps, const rbg_env_params *params,
+                                 const rbg_rollout_stats *stats,
+                                 const rbg_timestep *last_timestep,
+                                 const rbg_timestep *trajectory, int32_t *trajectory_action,
+                                 const rbg_stash *stash, int tick, int ready_delay,
+                                 void *stream) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_rollout: B < 0");
   if (n_steps < 1) return fail(RBG_E_PARAM, "rbg_connector_rollout: n_steps < 1");
   if (!params) return fail(RBG_E_NULL, "rbg_connector_rollout: NULL params");
@@ -1495,6 +1523,16 @@ int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_i
     a.stats = sp;
   }
   if (last_timestep) a.ts = to_ptrs(last_timestep);
+  const bool record = trajectory != nullptr || trajectory_action != nullptr;
+  if (record) {
+    if ((long long)n_steps * (long long)B > 0x7FFFFFFFll)
+      return fail(RBG_E_SHAPE, "rbg_connector_rollout_record: n_steps * B too large");
+    if (trajectory) {
+      if (int rc = check_align(a.g, trajectory->obs_grid, nullptr, nullptr)) return rc;
+      a.traj = to_ptrs(trajectory);
+    }
+    a.traj_action = trajectory_action;
+  }
   if (stash)
     if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_connector_rollout_prefetch")) return rc;
@@ -1502,7 +1540,7 @@ int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_i
   const bool wants_stats = stats && (stats->episodes || stats->connections_made ||
                                      stats->unconnected_agent_steps || stats->final_connections ||
                                      stats->final_path_length);
-  if (n_steps == 1 && last_timestep && last_timestep->obs_grid && !wants_stats) {
+  if (n_steps == 1 && last_timestep && last_timestep->obs_grid && !wants_stats && !record) {
     // "random policy + step" with the observation written: the HBM-bound shape of the per-step
     // kernel (one env per wave, 16 waves per CU in flight), not the LDS-resident rollout's
     EnvArgs e;
@@ -1517,12 +1555,20 @@ int rbg_connector_rollout_prefetch(int B, int m, int N, const rbg_state *state_i
   const dim3 grid((B + envs_per_block - 1) / envs_per_block), block(kBlock);
   const size_t lds = lds_bytes(a.g, lpb);
   hipStream_t st = (hipStream_t)stream;
-  if (lpb == 16) {
-    hipLaunchKernelGGL(connector_rollout_kernel<16>, grid, block, lds, st, a);
+  if (record) {
+    if (lpb == 16) {
+      hipLaunchKernelGGL((connector_rollout_kernel<16, true>), grid, block, lds, st, a);
+    } else if (lpb == 32) {
+      hipLaunchKernelGGL((connector_rollout_kernel<32, true>), grid, block, lds, st, a);
+    } else {
+      hipLaunchKernelGGL((connector_rollout_kernel<64, true>), grid, block, lds, st, a);
+    }
+  } else if (lpb == 16) {
+    hipLaunchKernelGGL((connector_rollout_kernel<16, false>), grid, block, lds, st, a);
   } else if (lpb == 32) {
-    hipLaunchKernelGGL(connector_rollout_kernel<32>, grid, block, lds, st, a);
+    hipLaunchKernelGGL((connector_rollout_kernel<32, false>), grid, block, lds, st, a);
   } else {
-    hipLaunchKernelGGL(connector_rollout_kernel<64>, grid, block, lds, st, a);
+    hipLaunchKernelGGL((connector_rollout_kernel<64, false>), grid, block, lds, st, a);
   }
   return check_hip(hipGetLastError(), "rbg_connector_rollout");
 }

@@ -917,6 +917,67 @@ def connector_rollout(state: StateBufs, policy_keys: torch.Tensor, t0: int, n_st
     return so, st, ts
 
 
+def alloc_trajectory(T: int, B: int, m: int, N: int, device, with_obs_grid: bool = True,
+                     aggregate: bool = False) -> TimestepBufs:
+    """Timestep buffers with a leading time axis [T, B, ...] + "action" [T, B, N]."""
+    flat = alloc_timestep(T * B, m, N, device, with_obs_grid=with_obs_grid, aggregate=aggregate)
+    traj = {k: v.view(T, B, *v.shape[1:]) for k, v in flat.items()}
+    traj["action"] = torch.empty((T, B, N), dtype=torch.int32, device=device)
+    return traj
+
+
+def connector_rollout_record(state: StateBufs, policy_keys: torch.Tensor, t0: int, n_steps: int,
+                             time_limit: int = 50, timestep_reward: float = -0.03,
+                             connected_reward: float = 0.1, auto_reset: bool = True,
+                             state_out: Optional[StateBufs] = None,
+                             trajectory: Optional[TimestepBufs] = None,
+                             stats: Optional[dict] = None, with_obs_grid: bool = True,
+                             epochs: Optional["EpochStash"] = None):
+    """connector_rollout that also records every step's timestep and action: returns
+    (state_out, stats, trajectory) with trajectory[field] of shape [n_steps, B, ...] -- row s is
+    what the s-th `VmapAutoResetWrapper(env).step` of the loop returns."""
+    B, m, _ = state["grid"].shape
+    N = state["start"].shape[1]
+    dev = state["grid"].device
+    T = int(n_steps)
+    policy_keys = check_keys(policy_keys)
+    if policy_keys.shape[0] != B:
+        raise ValueError("policy_keys and state disagree on B")
+    so = state_out if state_out is not None else alloc_state(B, m, N, dev)
+    st = stats if stats is not None else {}
+    for k in ROLLOUT_STATS:
+        if k in st:
+            _check(st[k], torch.int32, (B,), f"stats.{k}")
+    traj = trajectory if trajectory is not None else alloc_trajectory(T, B, m, N, dev, with_obs_grid)
+    flat = {}
+    for k, v in traj.items():
+        if tuple(v.shape[:2]) != (T, B) or not v.is_contiguous():
+            raise ValueError(f"trajectory.{k} must be contiguous with shape [n_steps, B, ...]")
+        flat[k] = v.view(T * B, *v.shape[2:])
+    action = flat.pop("action", None)
+    if action is not None:
+        _check(action, torch.int32, (T * B, N), "trajectory.action")
+    si, s_o = _state_struct(state, B, m, N), _state_struct(so, B, m, N)
+    sp = nat.RolloutStats(*[_ptr(st.get(k)) for k in ROLLOUT_STATS])
+    p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
+                      int(bool(auto_reset)))
+    tp = _timestep_struct(flat, T * B, m, N)
+    use_stash = epochs is not None and auto_reset
+    if use_stash:
+        if (epochs.B, epochs.m, epochs.N) != (B, m, N):
+            raise ValueError("epochs was built for another batch / grid / agent count")
+        epochs.before_launch()
+    rc = nat.lib().rbg_connector_rollout_record(
+        B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(), int(t0) & 0xFFFFFFFF, T,
+        C.byref(p), C.byref(sp), None, C.byref(tp), _ptr(action),
+        C.byref(epochs.struct) if use_stash else None, epochs.tick if use_stash else 0,
+        epochs.ready_delay() if use_stash else 0, _stream(dev))
+    if use_stash:
+        epochs.after_launch()
+    nat.check(rc, "rbg_connector_rollout_record")
+    return so, st, traj
+
+
 def random_actions(keys: torch.Tensor, t: int, action_mask: torch.Tensor,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     keys = check_keys(keys)

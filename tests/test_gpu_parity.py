@@ -437,6 +437,57 @@ def test_random_rollout_equals_stepwise_gpu(rbg, torch_mod):
     assert torch_mod.equal(fts["reward"], sts["reward"])
 
 
+@pytest.mark.parametrize("auto_reset,prefetch", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("m,N,B,steps", [(16, 10, 96, 40), (10, 5, 64, 45), (7, 4, 21, 30),
+                                         (32, 20, 8, 20), (12, 33, 12, 30), (16, 64, 6, 24)])
+def test_recorded_rollout_matches_oracle_step_by_step(rbg, oracle, m, N, B, steps, auto_reset,
+                                                      prefetch):
+    """rbg_connector_rollout_record: entry s of the trajectory == what the s-th
+    { rbg_random_actions; rbg_connector_step } of the loop returns, against the oracle's loop."""
+    env = rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N), time_limit=15)
+    if auto_reset:
+        env = rbg.VmapAutoResetWrapper(env, prefetch=prefetch)
+    keys, pkeys = _keys(rbg, 41, B), _keys(rbg, 42, B)
+    state, ts0 = env.reset(keys)
+    est, ets = oracle.connector_reset_batch(to_np(keys), m, N, threads=8)
+    t0 = 3
+    state, actions, traj = env.unwrapped.random_rollout(state, pkeys, t0, steps, record=True)
+    assert actions.shape == (steps, B, N) and traj.observation.grid.shape == (steps, B, N, m, m)
+    got = timestep_to_np(traj)
+    mask = ets["action_mask"]
+    for s in range(steps):
+        a = oracle.random_actions_batch(to_np(pkeys), t0 + s, mask)
+        assert (to_np(actions[s]) == a).all(), f"step {s}: actions"
+        ets = oracle.connector_step_batch(est, a, time_limit=15, auto_reset=auto_reset, threads=8)
+        assert_dicts_equal({k: v[s] for k, v in got.items()}, ets, f"step {s}: ")
+        mask = ets["action_mask"]
+    assert_dicts_equal(state_to_np(state), est, "final state.")
+    assert int((got["step_type"] == 2).sum()) > 0
+
+
+def test_recorded_rollout_at_full_size_equals_the_per_step_api(rbg, torch_mod):
+    """BASELINE configs[2] shape: 4096 envs x 50 steps recorded in one launch == 50 launches of
+    the per-step API (itself compared with the oracle at this size elsewhere)."""
+    from routing_board_generation_amd import ops
+
+    torch = torch_mod
+    B, m, N, T = 4096, 16, 10, 50
+    keys, pkeys = _keys(rbg, 51, B), _keys(rbg, 52, B)
+    st, ts = ops.connector_reset(keys, m, N)
+    so, _, traj = ops.connector_rollout_record(st, pkeys, 0, T)
+    cur, mask = {k: v.clone() for k, v in st.items()}, ts["action_mask"]
+    for t in range(T):
+        act = ops.random_actions(pkeys, t, mask)
+        cur, sts = ops.connector_step(cur, act, auto_reset=True)
+        mask = sts["action_mask"]
+        assert torch.equal(traj["action"][t], act), t
+        for k in ("obs_grid", "action_mask", "reward", "discount", "step_type", "obs_step_count",
+                  "num_connections", "ratio_connections", "total_path_length"):
+            assert torch.equal(traj[k][t], sts[k]), (t, k)
+    for k in ("grid", "step_count", "start", "target", "position"):
+        assert torch.equal(so[k], cur[k]), k
+
+
 # ------------------------------------------------------------------------------ offline dataset
 def test_board_dataset_generator(rbg, oracle):
     """BoardDatasetGeneratorJAX (dataset_generator_jax.py:20-141): dataset = generate_board over
