@@ -463,10 +463,12 @@ def main() -> None:
                     help="also time the K generator launches with three batches in flight on "
                          "three streams (off by default so that the rocprofv3 kernel statistics "
                          "of the default command describe lone launches only)")
-    ap.add_argument("--mode", choices=("all", "generator", "step-replay", "stream"), default="all",
+    ap.add_argument("--mode", choices=("all", "generator", "step-replay", "stream", "record"),
+                    default="all",
                     help="all = the driver's line; generator = the headline only; step-replay / "
-                         "stream = ONE launch population of connector_step_kernel each (the "
-                         "rocprofv3 passes under profiles/ are taken from these)")
+                         "stream = ONE launch population of connector_step_kernel each, record = "
+                         "the recording rollout only (the rocprofv3 passes under profiles/ are "
+                         "taken from these)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="developer option: CPU-only rehearsal of the multi-rank launch (gloo)")
     ap.add_argument("--all-configs", action="store_true",
@@ -486,6 +488,8 @@ def main() -> None:
         args.env_steps = args.rollout_steps = 0
     elif args.mode in ("step-replay", "stream"):
         args.steps, args.warmup, args.rollout_steps, args.cpu_sample = 1, 0, 0, 0
+    elif args.mode == "record":
+        args.steps, args.warmup, args.env_steps, args.cpu_sample = 1, 0, 0, 0
 
     import torch
     import torch.distributed as dist
@@ -816,6 +820,52 @@ def main() -> None:
                                                        args.stream_batch, copy_gbs)
 
     # ---------------------------------------------------------------- secondary: fused rollout
+    def recorded_rollout(launches):
+        """The random rollout RECORDING the trajectory (rbg_connector_rollout_record): every
+        step's observation, mask, reward, discount, step_type, extras and action land in
+        [T, B, ...] buffers -- the per-step API's output without its per-step launches."""
+        T_rec = args.rollout_steps
+        rec_bytes = 4 * N * m * m + 5 * N + 8 * N + 1 + 4 + 12 + 4 * N  # written per env-step
+        st, _ = ops.connector_reset(keys, m, N)
+        traj = ops.alloc_trajectory(T_rec, B, m, N, dev)
+        for i in range(2):
+            ops.connector_rollout_record(st, keys, i * T_rec, T_rec, state_out=st, trajectory=traj)
+        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t3 = time.perf_counter()
+        ce0.record()
+        for i in range(launches):
+            ops.connector_rollout_record(st, keys, (i + 2) * T_rec, T_rec, state_out=st,
+                                         trajectory=traj)
+        ce1.record()
+        barrier()
+        c_elapsed = time.perf_counter() - t3
+        cm = sharding.all_reduce_metrics({"env_steps": float(B * T_rec * launches),
+                                          "elapsed_s": c_elapsed}, device=dev)
+        rec_ms = ce0.elapsed_time(ce1) / launches
+        rec_gbs = B * T_rec * rec_bytes / (rec_ms * 1e-3) / 1e9
+        return {
+            "value": cm["env_steps"] / cm["elapsed_s"], "unit": "env-steps/s",
+            "launch_avg_ms": rec_ms, "steps_per_launch": T_rec, "launches": launches,
+            "roofline": {"bound": "hbm", "kernel": "connector_rollout_kernel<record>",
+                         "achieved": rec_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": rec_gbs / HBM_PEAK_GBS,
+                         "traffic": (measured_traffic("connector_rollout_kernel", B, "_record")
+                                     if T_rec == 50 else None),
+                         "algorithmic_bytes_per_launch": B * T_rec * rec_bytes,
+                         "bytes_per_env_step": rec_bytes},
+            "note": "rbg_connector_rollout_record: the rollout above with the timestep of EVERY "
+                    "step (observation, mask, reward, discount, step_type, extras) and the "
+                    "actions written to [steps, B, ...] buffers -- what the per-step API returns, "
+                    "one launch per steps_per_launch steps; resets walk inside the launch; "
+                    "`bench.py --mode record` runs only this (its rocprofv3 passes: "
+                    "profiles/*_record_*)"}
+
+    if args.mode == "record":
+        if rank == 0:
+            print(json.dumps({"mode": "record", **recorded_rollout(10)}), flush=True)
+        return
+
     rollout = None
     if args.rollout_steps > 0:
         launches = 10
@@ -867,42 +917,7 @@ def main() -> None:
                            "per-step observation traffic, so not HBM-bound (state in/out once "
                            "per launch)"}
 
-        # the same rollout RECORDING the trajectory (rbg_connector_rollout_record): every step's
-        # observation, mask, reward, discount, step_type, extras and action land in [T, B, ...]
-        # buffers -- the per-step API's output without its per-step launches
-        T_rec = args.rollout_steps
-        rec_bytes = 4 * N * m * m + 5 * N + 8 * N + 1 + 4 + 12 + 4 * N  # written per env-step
-        st, _ = ops.connector_reset(keys, m, N)
-        traj = ops.alloc_trajectory(T_rec, B, m, N, dev)
-        for i in range(2):
-            ops.connector_rollout_record(st, keys, i * T_rec, T_rec, state_out=st, trajectory=traj)
-        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
-        t3 = time.perf_counter()
-        ce0.record()
-        for i in range(launches):
-            ops.connector_rollout_record(st, keys, (i + 2) * T_rec, T_rec, state_out=st,
-                                         trajectory=traj)
-        ce1.record()
-        barrier()
-        c_elapsed = time.perf_counter() - t3
-        cm = sharding.all_reduce_metrics({"env_steps": float(B * T_rec * launches),
-                                          "elapsed_s": c_elapsed}, device=dev)
-        rec_ms = ce0.elapsed_time(ce1) / launches
-        rec_gbs = B * T_rec * rec_bytes / (rec_ms * 1e-3) / 1e9
-        del traj
-        rollout["recorded"] = {
-            "value": cm["env_steps"] / cm["elapsed_s"], "unit": "env-steps/s",
-            "launch_avg_ms": rec_ms, "steps_per_launch": T_rec,
-            "roofline": {"bound": "hbm", "kernel": "connector_rollout_kernel<record>",
-                         "achieved": rec_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": rec_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": B * T_rec * rec_bytes,
-                         "bytes_per_env_step": rec_bytes},
-            "note": "rbg_connector_rollout_record: the rollout above with the timestep of EVERY "
-                    "step (observation, mask, reward, discount, step_type, extras) and the "
-                    "actions written to [steps, B, ...] buffers -- what the per-step API returns, "
-                    "one launch per steps_per_launch steps; resets walk inside the launch"}
+        rollout["recorded"] = recorded_rollout(launches)
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample != 0:
