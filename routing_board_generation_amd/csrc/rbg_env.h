@@ -83,19 +83,35 @@ __device__ __forceinline__ void store_obs(const SubWave<LPB> &sw, const uint32_t
                                           const Geo &g, int N, int32_t *__restrict__ obs) {
   const int n3 = 3 * N, lane = sw.l;
   if ((g.m & 3) == 0) {
+    // Four cells per lane, all N planes from registers.  Values fit 16 bits (<= 3N <= 192), so the
+    // arithmetic runs on two packed pairs: u = (v - 1 - 3i) mod 3N is carried from plane to plane
+    // (u - 3, wrapped by an unsigned min against u - 3 + 3N), the view is (u + 1) where the cell is
+    // not empty.  14 VALU instructions per plane and lane instead of 22.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const u16x2 one = {1, 1}, three = {3, 3};
+    const u16x2 wrap = {(unsigned short)n3, (unsigned short)n3};
     for (int idx = lane * 4; idx < g.n; idx += LPB * 4) {
       const int r = div_m(g, idx);
       const uint4 v = *reinterpret_cast<const uint4 *>(&board[pad_index(g, r, idx - r * g.m)]);
+      const u16x2 p01 = __builtin_bit_cast(u16x2, v.x | (v.y << 16));
+      const u16x2 p23 = __builtin_bit_cast(u16x2, v.z | (v.w << 16));
+      // 32-bit masks of the cells that hold a wire (an empty cell stays 0 in every view)
+      const uint32_t mx = v.x ? 0x0000FFFFu : 0u, my = v.y ? 0xFFFF0000u : 0u;
+      const uint32_t mz = v.z ? 0x0000FFFFu : 0u, mw = v.w ? 0xFFFF0000u : 0u;
+      u16x2 u01 = p01 - one, u23 = p23 - one;
+      int32_t *out = obs + idx;
       for (int i = 0; i < N; ++i) {
-        int4 o;
-        o.x = obs_value(v.x, 3 * i, n3);
-        o.y = obs_value(v.y, 3 * i, n3);
-        o.z = obs_value(v.z, 3 * i, n3);
-        o.w = obs_value(v.w, 3 * i, n3);
+        const uint32_t s01 = __builtin_bit_cast(uint32_t, (u16x2)(u01 + one));
+        const uint32_t s23 = __builtin_bit_cast(uint32_t, (u16x2)(u23 + one));
         // write-once stream: non-temporal keeps it from evicting the states in L2/Infinity Cache
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        v4i ov = {o.x, o.y, o.z, o.w};
-        __builtin_nontemporal_store(ov, reinterpret_cast<v4i *>(&obs[(size_t)i * g.n + idx]));
+        const v4i ov = {(int)(s01 & mx), (int)((s01 & my) >> 16), (int)(s23 & mz),
+                        (int)((s23 & mw) >> 16)};
+        __builtin_nontemporal_store(ov, reinterpret_cast<v4i *>(out));
+        out += g.n;
+        const u16x2 t01 = u01 - three, t23 = u23 - three;
+        u01 = __builtin_elementwise_min(t01, (u16x2)(t01 + wrap));
+        u23 = __builtin_elementwise_min(t23, (u16x2)(t23 + wrap));
       }
     }
   } else {
