@@ -29,6 +29,9 @@ def main() -> None:
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--n-steps", type=int, default=50)
+    ap.add_argument("--one-launch-per-epoch", action="store_true",
+                    help="collect the epoch's trajectory with ONE kernel launch "
+                         "(env.random_rollout(..., record=True)) instead of n-steps env.step calls")
     args = ap.parse_args()
 
     rank, local_rank, world = sharding.init_distributed()
@@ -37,8 +40,11 @@ def main() -> None:
     # setup_train._make_raw_env + setup_env (setup_train.py:148-167)
     generator = rbg.ParallelRandomWalkGenerator(grid_size=args.grid_size,
                                                 num_agents=args.num_agents)
-    env = rbg.VmapAutoResetWrapper(
-        rbg.MultiToSingleWrapper(rbg.Connector(generator=generator, donate=True)))
+    if args.one_launch_per_epoch:  # per-agent rewards: the recording rollout returns those
+        env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=generator))
+    else:
+        env = rbg.VmapAutoResetWrapper(
+            rbg.MultiToSingleWrapper(rbg.Connector(generator=generator, donate=True)))
 
     # setup_training_state (setup_train.py:390-403): split the key, reset this rank's shard
     key = rbg.PRNGKey(0, device=dev)
@@ -53,7 +59,16 @@ def main() -> None:
         episodes = torch.zeros((), dtype=torch.int64, device=dev)
         ep_return = torch.zeros((), dtype=torch.float64, device=dev)
         connections = torch.zeros((), dtype=torch.int64, device=dev)
-        for _ in range(args.n_steps):
+        if args.one_launch_per_epoch:
+            # the same n_steps of RandomAgent + env.step, recorded by one launch: every field of
+            # `traj` has a leading time axis [n_steps, B, ...] (what lax.scan stacks in run_epoch)
+            state, actions, traj = env.random_rollout(state, policy_keys, t, args.n_steps, record=True)
+            last = traj.last()
+            episodes += last.sum()
+            ep_return += traj.reward.sum()
+            connections += (traj.extras["num_connections"] * last).sum()
+            t += args.n_steps
+        for _ in range(0 if args.one_launch_per_epoch else args.n_steps):
             # RandomAgent: uniform over the legal actions of every agent
             action = ops.random_actions(policy_keys, t, timestep.observation.action_mask)
             state, timestep = env.step(state, action)

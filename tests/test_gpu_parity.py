@@ -994,6 +994,14 @@ def test_random_agent_loop_example_runs():
     lines = [ln for ln in out.splitlines() if ln.startswith("epoch")]
     assert len(lines) == 2 and "episodes" in lines[1], out
     assert int(lines[1].split(" GPU(s), ")[1].split(" episodes")[0]) > 256, out
+    # the same epochs collected by one recording launch each: same episodes, same connections
+    out2 = subprocess.check_output(
+        [sys.executable, os.path.join(root, "examples", "random_agent_loop.py"), "--epochs", "2",
+         "--batch-per-gpu", "512", "--n-steps", "60", "--one-launch-per-epoch"], text=True,
+        cwd=root, timeout=600)
+    lines2 = [ln for ln in out2.splitlines() if ln.startswith("epoch")]
+    counts = lambda ln: ln.split(" GPU(s), ")[1].split(", mean step reward")[0]  # noqa: E731
+    assert [counts(ln) for ln in lines2] == [counts(ln) for ln in lines], (out, out2)
 
 
 @pytest.mark.parametrize("m,N,B,steps,tl", [(16, 10, 4096, 110, 50),  # BASELINE configs[2], full size
