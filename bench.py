@@ -566,6 +566,28 @@ def main() -> None:
     total_elapsed = metrics["elapsed_s"]  # max over ranks
     value = metrics["boards"] / total_elapsed
 
+    # What actually bounds the launch: the serial latency of its longest board.  Timed live: the
+    # board with the most walk iterations launched ALONE (one wave), same kernel, same outputs.
+    longest = int(iters.argmax().item())
+    lkeys = keys[longest:longest + 1].clone()
+    lout = ops.prw_generate(lkeys, m, N, split_first=True, want_solved=False, want_train=True,
+                            want_state=True, want_iters=True)
+    lstep = ops.prw_generate_launcher(lkeys, m, N, True, lout)
+    for _ in range(20):
+        lstep()
+    le0, le1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    le0.record()
+    for _ in range(200):
+        lstep()
+    le1.record()
+    torch.cuda.synchronize(dev)
+    longest_ms = le0.elapsed_time(le1) / 200
+    serial = {"bound": "longest_board_latency", "floor_ms": longest_ms,
+              "frac": longest_ms / kernel_avg_ms, "walk_iters_of_that_board": int(iters[longest]),
+              "note": "the board with the most walk iterations launched alone (one wavefront; 200 "
+                      "launches, HIP events): a board is a chain of dependent iterations, so no "
+                      "launch of this batch can be shorter; frac = that floor / this launch"}
+
     bpb = generator_bytes_per_board(m, N)
     achieved = B * bpb / (kernel_avg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "prw_generate_kernel<32> (2 boards per wavefront)",
@@ -576,6 +598,7 @@ def main() -> None:
                 "bytes_per_board": bpb, "boards_per_launch": B,
                 "kernel_avg_ms": kernel_avg_ms,
                 "issue": issue_roofline("prw_generate_kernel", B, kernel_avg_ms),
+                "serial": serial,
                 "note": "latency-bound walk (serial dependent iterations per board): HBM fraction "
                         "reported for the record, the issue-based figure beside it; see DESIGN.md"}
 
