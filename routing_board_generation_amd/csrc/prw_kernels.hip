@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kBlock) void prw_generate_kernel(GenArgs a) {
   }
 }
 
+#ifndef RBG_TU_RECORD  // (SequentialRandomWalk kernel: not part of the recording-rollout unit)
 // SequentialRandomWalkBoard.generate / SequentialRandomWalkGenerator.__call__ (one board per wave)
 __global__ __launch_bounds__(kBlock) void seq_rw_generate_kernel(GenArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
@@ -175,6 +176,8 @@ __global__ __launch_bounds__(kBlock) void seq_rw_generate_kernel(GenArgs a) {
     if (a.iters) a.iters[b] = attempts;
   }
 }
+
+#endif  // !RBG_TU_RECORD
 
 // ParallelRandomWalkGenerator(stream = "philox") (rbg_walk_philox.h): N lanes per board suffice
 template <int LPB>
@@ -278,6 +281,7 @@ struct UniformArgs {
   uint32_t *key_out;
 };
 
+#ifndef RBG_TU_RECORD  // (not part of the recording-rollout unit)
 // UniformRandomGenerator.__call__ (uniform_generator.py:70-109)
 __global__ __launch_bounds__(kBlock) void uniform_generate_kernel(UniformArgs a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
@@ -318,6 +322,8 @@ __global__ __launch_bounds__(kBlock) void uniform_generate_kernel(UniformArgs a)
     if (a.step_count) a.step_count[b] = 0;
   }
 }
+
+#endif  // !RBG_TU_RECORD
 
 // Pre-generated next-episode states (include/rbg_prw.h::rbg_stash).  `next` of env b is the
 // State the auto-reset of an episode with State.key == tag[b] must produce.
@@ -601,6 +607,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 #endif
 }
 
+#ifndef RBG_TU_RECORD  // (not part of the recording-rollout unit)
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_kernel(EnvArgs a) {
   connector_body<kModeReset>(a);
 }
@@ -610,6 +617,8 @@ __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_obser
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_kernel(EnvArgs a) {
   connector_body<kModeStep>(a);
 }
+
+#endif  // !RBG_TU_RECORD
 
 // Producer of the stash: for every env whose entry is not the one its running episode will need
 // (tag != refill_key), generate G(split(refill_key)[0]) and publish it.  One env per sub-wave
@@ -752,9 +761,11 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLL
     }
     const int row = s * a.B + b;  // of the trajectory arrays
     if constexpr (kRecord) {
+      __builtin_amdgcn_sched_barrier(0);  // (keeps the writers' address arithmetic out of the step)
       if (a.traj_action && is_agent) a.traj_action[(size_t)row * N + l] = act;
       write_step_outcome(sw, res, a.p, N, row, a.traj);
       write_extras(sw, board, g, N, row, ag, a.traj);  // of the terminal state when it is one
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (res.last) {  // per env
       episodes = uni<LPB>(episodes + 1);
@@ -778,7 +789,11 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLL
       }
     }
     // (after an auto-reset: the observation of the episode that starts, like the wrapper's)
-    if constexpr (kRecord) write_observation(sw, board, g, N, row, ag, step_count, a.traj, bits);
+    if constexpr (kRecord) {
+      __builtin_amdgcn_sched_barrier(0);
+      write_observation(sw, board, g, N, row, ag, step_count, a.traj, bits);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   store_state(sw, board, g, N, b, ag, step_count, key, a.out);
   write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
@@ -791,6 +806,7 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLL
   }
 }
 
+#ifndef RBG_TU_RECORD  // (not part of the recording-rollout unit)
 // BoardDatasetGeneratorJAX.__call__ (rl_training/offline_generation/dataset_generator_jax.py
 // :112-141): key, _ = split(key); which = randint(key, (), 0, n_boards); State from the stored
 // heads/targets of board `which`.  [3P] jax/_src/random.py::_randint: k1, k2 = split(key);
@@ -1047,6 +1063,26 @@ __global__ void prw_step_agent_kernel(const int32_t *__restrict__ grid, int B, i
   }
 }
 
+#endif  // !RBG_TU_RECORD
+
+// The recording rollout's launch, in a function of its own so that it can live in a translation
+// unit of its own (csrc/prw_record.hip): it is the one kernel of the library that the max-ilp
+// scheduler of the main unit slows down (9.1 instead of 8.1 us per step), see _native.py.
+#if defined(RBG_TU_RECORD) || !defined(RBG_RECORD_TU_SEPARATE)
+int launch_rollout_record(const RolloutArgs &a, int lpb, unsigned grid, size_t lds,
+                          hipStream_t st) {
+  if (lpb == 16) {
+    hipLaunchKernelGGL((connector_rollout_kernel<16, true>), dim3(grid), dim3(kBlock), lds, st, a);
+  } else if (lpb == 32) {
+    hipLaunchKernelGGL((connector_rollout_kernel<32, true>), dim3(grid), dim3(kBlock), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((connector_rollout_kernel<64, true>), dim3(grid), dim3(kBlock), lds, st, a);
+  }
+  return (int)hipGetLastError();
+}
+#endif
+
+#ifndef RBG_TU_RECORD  // (not part of the recording-rollout unit)
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
@@ -1127,7 +1163,22 @@ bool state_complete(const rbg_state *s) {
   return s && s->grid && s->step_count && s->start && s->target && s->position && s->key;
 }
 
+#endif  // !RBG_TU_RECORD
+
 }  // namespace
+
+#if defined(RBG_TU_RECORD)
+// (RolloutArgs is a type of this unit's anonymous namespace: the same source, the same layout)
+extern "C" __attribute__((visibility("hidden"))) int rbg_internal_rollout_record(
+    const void *args, int lpb, unsigned grid, size_t lds, void *stream) {
+  return launch_rollout_record(*static_cast<const RolloutArgs *>(args), lpb, grid, lds,
+                               (hipStream_t)stream);
+}
+#else
+#if defined(RBG_RECORD_TU_SEPARATE)
+extern "C" __attribute__((visibility("hidden"))) int rbg_internal_rollout_record(
+    const void *args, int lpb, unsigned grid, size_t lds, void *stream);
+#endif
 
 extern "C" {
 
@@ -1556,13 +1607,13 @@ int rbg_connector_rollout_record(int B, int m, int N, const rbg_state *state_in,
   const size_t lds = lds_bytes(a.g, lpb);
   hipStream_t st = (hipStream_t)stream;
   if (record) {
-    if (lpb == 16) {
-      hipLaunchKernelGGL((connector_rollout_kernel<16, true>), grid, block, lds, st, a);
-    } else if (lpb == 32) {
-      hipLaunchKernelGGL((connector_rollout_kernel<32, true>), grid, block, lds, st, a);
-    } else {
-      hipLaunchKernelGGL((connector_rollout_kernel<64, true>), grid, block, lds, st, a);
-    }
+#if defined(RBG_RECORD_TU_SEPARATE)
+    return check_hip((hipError_t)rbg_internal_rollout_record(&a, lpb, grid.x, lds, stream),
+                     "rbg_connector_rollout_record");
+#else
+    return check_hip((hipError_t)launch_rollout_record(a, lpb, grid.x, lds, st),
+                     "rbg_connector_rollout_record");
+#endif
   } else if (lpb == 16) {
     hipLaunchKernelGGL((connector_rollout_kernel<16, false>), grid, block, lds, st, a);
   } else if (lpb == 32) {
@@ -1685,3 +1736,4 @@ int rbg_prw_step_agent(const int32_t *grid, int B, int m, int N, const int32_t *
 }
 
 }  // extern "C"
+#endif  // !RBG_TU_RECORD

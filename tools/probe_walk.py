@@ -117,7 +117,7 @@ def main():
         subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
                               fl.split() + ["-o", so, nat.SRC_PATH])
         lib = C.CDLL(so)
-        for B in (4096, 16384):
+        for B in (100, 4096, 16384):
             runs = [time_generate(B, args.m, args.n, reps=300, lib=lib)[0] for _ in range(3)]
             print(f"flags {fl!r}: B={B:5d}  " + "  ".join(f"{u:7.2f}" for u in runs) + " us",
                   flush=True)
