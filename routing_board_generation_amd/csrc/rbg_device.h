@@ -62,30 +62,6 @@ __device__ __forceinline__ void threefry_second_half(const TfState &t, uint32_t 
   y1 = x1;
 }
 
-// The second half cut once more (rounds 9-12 | 13-20), for schedules that want four rounds to
-// interleave with other work.
-__device__ __forceinline__ void threefry_rounds_9_12(TfState &t) {
-  uint32_t x0 = t.x0, x1 = t.x1;
-  RBG_TF_ROUND(13) RBG_TF_ROUND(15) RBG_TF_ROUND(26) RBG_TF_ROUND(6)
-  x0 += t.k0;
-  x1 += t.k1 + 3u;
-  t.x0 = x0;
-  t.x1 = x1;
-}
-__device__ __forceinline__ void threefry_rounds_13_20(const TfState &t, uint32_t &y0,
-                                                      uint32_t &y1) {
-  uint32_t x0 = t.x0, x1 = t.x1;
-  const uint32_t k0 = t.k0, k1 = t.k1, k2 = t.k2;
-  RBG_TF_ROUND(17) RBG_TF_ROUND(29) RBG_TF_ROUND(16) RBG_TF_ROUND(24)
-  x0 += k1;
-  x1 += k2 + 4u;
-  RBG_TF_ROUND(13) RBG_TF_ROUND(15) RBG_TF_ROUND(26) RBG_TF_ROUND(6)
-  x0 += k2;
-  x1 += k0 + 5u;
-  y0 = x0;
-  y1 = x1;
-}
-
 __device__ __forceinline__ void threefry(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1,
                                          uint32_t &y0, uint32_t &y1) {
   const TfState t = threefry_first_half(k0, k1, x0, x1);

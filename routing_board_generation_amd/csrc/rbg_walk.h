@@ -232,11 +232,7 @@ template <int LPB>
 __device__ __forceinline__ float prng_second(uint32_t *W, const PrngLanes<LPB> &p,
                                              const TfState &t) {
   uint32_t y0, y1;
-#if defined(RBG_WALK_TF_SPLIT3)  // probe: rounds 9-12 were issued with the choice code
-  threefry_rounds_13_20(t, y0, y1);
-#else
   threefry_second_half(t, y0, y1);
-#endif
   W[p.w_y0] = y0;
   W[p.w_y1] = y1;
   return bits_to_unit12(y0);  // 1 + uniform; meaningful in the r_uni lanes
@@ -437,11 +433,6 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
       u_next = prng_round_multi(W, N, sw.lane, kcur);
     }
     __builtin_amdgcn_sched_barrier(0);
-#if defined(RBG_WALK_TF_SPLIT3)
-    // probe: four more rounds in the same scheduling region as the availability / choice code
-    // (independent of it), so that a wave alone on its SIMD has two instruction chains to issue
-    if (kEvals >= 1) threefry_rounds_9_12(tf);
-#endif
 
     // (lanes without an agent sit between walls: no `is_agent` term needed)
     const bool own_ul = ul == wire, own_ur = ur == wire, own_dl = dl == wire, own_dr = dr == wire;
