@@ -11,7 +11,7 @@
 
 #define CHAIN(name, body)                                                            \
   __global__ void name(uint32_t *out, uint64_t *cycles) {                            \
-    uint32_t x = threadIdx.x, y = threadIdx.x * 7 + 1, z = 0x9E3779B9u;              \
+    uint32_t x = threadIdx.x, y = threadIdx.x * 7 + 1, z = 0x9E3779B9u, w = threadIdx.x + 5;              \
     const uint64_t r0 = __builtin_amdgcn_s_memrealtime();                            \
     const uint64_t t0 = __builtin_amdgcn_s_memtime();                                \
     for (int i = 0; i < 16; ++i) {                                                   \
@@ -19,7 +19,7 @@
     }                                                                                \
     const uint64_t t1 = __builtin_amdgcn_s_memtime();                                \
     const uint64_t r1 = __builtin_amdgcn_s_memrealtime();                            \
-    out[threadIdx.x] = x + y;                                                        \
+    out[threadIdx.x] = x + y + w + z;                                                        \
     if (threadIdx.x == 0) {                                                          \
       cycles[0] = t1 - t0;                                                           \
       cycles[1] = r1 - r0; /* 100 MHz ticks */                                       \
@@ -39,6 +39,12 @@ CHAIN(k_round_rot_first, asm volatile("v_alignbit_b32 %2, %1, %1, 13\n v_add_u32
                                       : "+v"(x), "+v"(y), "+v"(z));)
 // two independent chains interleaved (what a second wave, or a second board, would add)
 CHAIN(k_two_chains, asm volatile("v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %2" : "+v"(x), "+v"(y) : "v"(z));)
+// scalar ALU: a dependent chain, and one independent s_add behind every dependent v_add
+CHAIN(k_salu, asm volatile("s_add_u32 %0, %0, 1" : "+s"(z) : : "scc");)
+CHAIN(k_valu_salu, asm volatile("v_add_u32 %0, %0, %2\n s_add_u32 %1, %1, 1" : "+v"(x), "+s"(z) : "v"(y) : "scc");)
+// a dependent v_add with TWO independent v_adds behind it (how far does the 4-cycle slot go?)
+CHAIN(k_three_chains, asm volatile("v_add_u32 %0, %0, %2\n v_add_u32 %1, %1, %2\n v_add_u32 %3, %3, %2"
+                                   : "+v"(x), "+v"(y) , "+v"(z), "+v"(w) : );)
 // dependent DPP move
 CHAIN(k_dpp, asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x));)
 
@@ -61,6 +67,9 @@ int main() {
   RUN(k_round, "Threefry round (add, alignbit, xor)")
   RUN(k_round_rot_first, "Threefry round (alignbit, add, xor)")
   RUN(k_two_chains, "PAIR of independent v_add_u32")
+  RUN(k_three_chains, "TRIPLE of independent v_add_u32")
+  RUN(k_salu, "dependent s_add_u32")
+  RUN(k_valu_salu, "dependent v_add_u32 + independent s_add_u32")
   RUN(k_dpp, "dependent s_nop 1 + v_mov_b32_dpp")
   return 0;
 }
