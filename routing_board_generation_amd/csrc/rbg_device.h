@@ -110,6 +110,10 @@ __device__ __forceinline__ float bits_to_uniform(uint32_t bits) {
 __device__ __forceinline__ float bits_to_unit12(uint32_t bits) {
   return __uint_as_float((bits >> 9) | 0x3F800000u);
 }
+// 1 - uniform(bits), exactly (see above): what jax's choice multiplies cum[-1] by
+__device__ __forceinline__ float bits_to_one_minus_uniform(uint32_t bits) {
+  return __fsub_rn(2.0f, bits_to_unit12(bits));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Wave / sub-wave helpers

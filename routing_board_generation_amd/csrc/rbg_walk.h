@@ -235,7 +235,9 @@ __device__ __forceinline__ float prng_second(uint32_t *W, const PrngLanes<LPB> &
   threefry_second_half(t, y0, y1);
   W[p.w_y0] = y0;
   W[p.w_y1] = y1;
-  return bits_to_unit12(y0);  // 1 + uniform; meaningful in the r_uni lanes
+  // 1 - uniform, converted here: in the shadow of the move's LDS round trip the chain of Threefry
+  // rounds leaves issue slots free, the availability code that consumes it does not
+  return bits_to_one_minus_uniform(y0);  // meaningful in the r_uni lanes
 }
 
 // Start of the pipeline: the chain key goes to its W slot.
@@ -252,7 +254,7 @@ __device__ __forceinline__ float prng_round_single(uint32_t *W, const PrngLanes<
   W[p.w_y0] = y.x;
   W[p.w_y1] = y.y;
   wave_lds_fence();
-  return bits_to_unit12(y.x);
+  return bits_to_one_minus_uniform(y.x);
 }
 
 // One whole round when 2N + 2 > 64 (full-wave boards with N >= 32): two or three evaluations.
@@ -269,7 +271,7 @@ __device__ __forceinline__ float prng_round_multi(uint32_t *W, int N, int lane, 
     const uint32_t c0 = r_uni ? 0u : r_split ? (uint32_t)(s - N) : (uint32_t)(s - twoN);
     const uint32_t c1 = r_uni ? 0u : r_split ? (uint32_t)s : (uint32_t)(s - twoN + 2);
     const uint2 y = threefry_call(r_uni ? kk.x : kcur.a, r_uni ? kk.y : kcur.b, c0, c1);
-    if (r_uni) u = bits_to_unit12(y.x);
+    if (r_uni) u = bits_to_one_minus_uniform(y.x);
     W[r_split ? s - N : dump] = y.x;
     W[r_split ? s : dump + 1] = y.y;
     if (base == (twoN & ~(kWaveSize - 1))) {  // wave-uniform: the call that holds slots 2N, 2N+1
@@ -369,7 +371,7 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
 
   // pipeline prologue: W <- split(k_0, N), kcur <- k_1; then u <- u(0), W <- split(k_1, N), ...
   const PrngLanes<LPB> pl = prng_lanes<LPB>(N, l);
-  float u;  // 1 + uniform of this lane's agent for the coming iteration
+  float u;  // 1 - uniform of this lane's agent for the coming iteration
   const PrngLanes<LPB> pl1 = prng_lanes<LPB>(N, l, 1);  // second evaluation (kEvals == 2)
   if (kEvals >= 1) {
     prng_seed(W, N, l, kcur);
@@ -453,8 +455,8 @@ __device__ __forceinline__ void prw_walk_impl(const SubWave<LPB> &sw, uint32_t *
 
     // ---- _select_action (:205-230): keys = split(key, N); choice(p = available) -----------
     // choice: cum = cumsum(p); r = cum[-1] * (1 - uniform(key_i)); first index with cum >= r.
-    // u12 = 1 + uniform, and 1 - uniform == 2 - u12 exactly (rbg_device.h::bits_to_unit12)
-    const float rsel = __fmul_rn(c4, __fsub_rn(2.0f, u));
+    // (u = 1 - uniform, rbg_device.h::bits_to_one_minus_uniform)
+    const float rsel = __fmul_rn(c4, u);
     int dir = 3;
     if (c3 >= rsel) dir = 2;
     if (c2 >= rsel) dir = 1;
