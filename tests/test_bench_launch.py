@@ -40,3 +40,21 @@ def test_bench_single_rank_rehearsal_needs_no_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 1 and line["boards"] == 4096 * 2
+
+
+def test_bench_reads_each_traffic_figure_from_its_own_profile():
+    """roofline.traffic comes from the committed rocprofv3 PMC pass of the SAME launch population
+    (the step line once carried the bytes of the 65 536-env stream run)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    gen = bench.measured_traffic("prw_generate_kernel", 4096)
+    step = bench.measured_traffic("connector_step_kernel", 4096, "_step")
+    stream = bench.measured_traffic("connector_step_kernel", 65536, "_stream", 65536)
+    rec = bench.measured_traffic("connector_rollout_kernel", 4096, "_record")
+    assert 5.2e6 < gen < 5.6e6          # 4096 x 1284 B algorithmic
+    assert 5.3e7 < step < 5.6e7         # 4096 x 12 979 B
+    assert 8.5e8 < stream < 8.8e8       # 65 536 x 12 979 B
+    assert 2.13e9 < rec < 2.17e9        # 50 x 4096 x 10 427 B + the State
+    assert bench.measured_traffic("connector_step_kernel", 4096, "_stream", 65536) is None
+    assert bench.measured_issue("prw_generate_kernel", 4096)["valu_insts_per_launch"] > 1e7
