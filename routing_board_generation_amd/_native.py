@@ -18,7 +18,7 @@ ABI_VERSION = 7
 # -amdgpu-sched-strategy=max-ilp: the walk's straggler boards run one wave per SIMD, where an
 # instruction that depends on its predecessor issues after ~8 cycles and an independent one after
 # ~4 (tools/microbench/dep_latency.hip); the default scheduler (occupancy-first) leaves the
-# availability compares and the Threefry rounds as dependent runs (35.3 -> 31.8 us)
+# availability compares and the Threefry rounds as dependent runs (35.3 -> 31.7 us)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
                "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
@@ -124,13 +124,8 @@ SIGNATURES = {
 
 
 def build_native(force: bool = False) -> str:
-    """Compile csrc/ for gfx950 into lib/librbg_prw.so (hipcc cross-compiles without a GPU).
-
-    Two translation units of the same source: csrc/prw_kernels.hip with HIPCC_FLAGS (max-ilp
-    scheduling; -DRBG_RECORD_TU_SEPARATE leaves the recording rollout out) and
-    csrc/prw_record.hip, the recording rollout alone, with the default scheduler.  The one-command
-    form `hipcc HIPCC_FLAGS -o lib.so csrc/prw_kernels.hip` is also a complete library (the
-    tests' variant builds and the probes use it)."""
+    """Compile csrc/prw_kernels.hip for gfx950 into lib/librbg_prw.so (hipcc cross-compiles
+    without a GPU)."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     csrc = os.path.dirname(SRC_PATH)
     sources = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [HEADER_PATH, __file__]
@@ -138,20 +133,7 @@ def build_native(force: bool = False) -> str:
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in sources))
     if force or stale:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
-        default_sched = [f for f in compile_flags
-                         if f not in ("-mllvm", "-amdgpu-sched-strategy=max-ilp")]
-        lib_dir = os.path.dirname(LIB_PATH)
-        main_o, rec_o = os.path.join(lib_dir, "prw_kernels.o"), os.path.join(lib_dir, "prw_record.o")
-        jobs = [subprocess.Popen([hipcc] + compile_flags + ["-DRBG_RECORD_TU_SEPARATE", "-c",
-                                                             SRC_PATH, "-o", main_o]),
-                subprocess.Popen([hipcc] + default_sched + ["-c", os.path.join(csrc, "prw_record.hip"),
-                                                             "-o", rec_o])]
-        for j in jobs:
-            if j.wait() != 0:
-                raise subprocess.CalledProcessError(j.returncode, j.args)
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH,
-                               main_o, rec_o])
+        subprocess.check_call([hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC_PATH])
     return LIB_PATH
 
 

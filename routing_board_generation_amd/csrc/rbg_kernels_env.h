@@ -1,0 +1,196 @@
+// rbg_kernels_env.h -- Connector reset / observe / step (one env per wavefront, one body, three
+// kernels) and the producer of the next-episode stash.
+#pragma once
+#include "rbg_kernels_stash.h"
+
+namespace {
+
+struct EnvArgs {
+  const uint32_t *keys;  // reset only
+  int B, N;
+  Geo g;
+  StatePtrs in;   // step / observe
+  StatePtrs out;
+  const int32_t *action;
+  rbg_env_params p;
+  TimestepPtrs ts;
+  int mode;  // 0 reset (generate), 1 observe existing state, 2 step
+  StashPtrs stash;  // all NULL when resets are always generated inline
+  int tick, ready_delay;
+  const uint32_t *policy_keys;  // step only: non-NULL = the action comes from the masked-uniform
+  uint32_t policy_t;            // random policy (rbg_random_actions) of global step policy_t
+};
+
+#ifndef RBG_ENV_WPB
+#define RBG_ENV_WPB 4
+#endif
+constexpr int kEnvWavesPerBlock = RBG_ENV_WPB;  // waves (envs) per workgroup of the env kernels
+
+// One body, three kernels (reset / observe / step) so that every launch population has its own
+// name in a rocprofv3 kernel trace.
+enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
+
+template <int MODE>
+__device__ __forceinline__ void connector_body(const EnvArgs &a) {
+#if defined(RBG_PROBE_STEP_TIMES)  // developer probe (tools/probe_step.py --times)
+  const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
+#endif
+  const int lane = threadIdx.x & (kWaveSize - 1);
+  const SubWave<64> sw(lane);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * kEnvWavesPerBlock + wib;
+  if (b >= a.B) return;
+  uint32_t *board = g_lds + wib * slab_words<64>(a.g);
+  uint32_t *W = board + board_words(a.g);
+  const Geo g = a.g;
+  const int N = a.N;
+  AgentRegs ag = {0, 0, 0, 0, 0, 0};
+
+  if constexpr (MODE == kModeReset) {  // ---- Connector.reset ----------------------------------
+    Key2 kin;
+    kin.a = a.keys[2 * (size_t)b];
+    kin.b = a.keys[2 * (size_t)b + 1];
+    const Key2 key = regenerate(sw, board, W, g, N, kin, ag);
+    store_state(sw, board, g, N, b, ag, 0, key, a.out);
+    request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+    write_observation(sw, board, g, N, b, ag, 0, a.ts,
+                      lane < N ? action_mask_bits(board, g, ag, lane) : 1u);
+    write_extras(sw, board, g, N, b, ag, a.ts);
+    write_restart(N, b, lane, a.ts);
+    return;
+  }
+
+  int step_count;
+  Key2 key;
+  load_state(sw, board, g, N, b, a.in, ag, step_count, key);
+
+  if constexpr (MODE == kModeObserve) {  // ---- observe an existing state (restart timestep) ---
+    write_observation(sw, board, g, N, b, ag, step_count, a.ts,
+                      lane < N ? action_mask_bits(board, g, ag, lane) : 1u);
+    write_extras(sw, board, g, N, b, ag, a.ts);
+    write_restart(N, b, lane, a.ts);
+    return;
+  }
+
+  // ---- Connector.step --------------------------------------------------------------------------
+  int act = 0;
+  if (a.policy_keys) {
+    // policy fused into the step launch: the mask rbg_random_actions would read from the previous
+    // timestep is the mask of the state just loaded
+    Key2 pk;
+    pk.a = a.policy_keys[2 * (size_t)b];
+    pk.b = a.policy_keys[2 * (size_t)b + 1];
+    if (lane < N)
+      act = random_policy_action(pk, a.policy_t, (uint32_t)lane, action_mask_bits(board, g, ag, lane));
+  } else if (lane < N) {
+    act = a.action[(size_t)b * N + lane];
+  }
+  const StashProbe probe = stash_probe_issue(a.stash, a.B, b, lane);  // in flight during the step
+  RowPrefetch pf;
+  pf.row = -1;
+  if (a.p.auto_reset && a.stash.tag && step_count + 1 >= a.p.time_limit && (g.m & 3) == 0 &&
+      g.n <= 4 * kWaveSize)  // wave-uniform
+    pf = stash_row_issue(a.stash.next, g, N,
+                         stash_probe_row(a.stash, probe, a.B, b, lane, key, a.tick), lane);
+#if defined(RBG_PROBE_SKIP_STEP)  // developer probe: load -> store only (wrong results)
+  StepResult res;
+  res.was_connected = res.connected = res.done = res.last = false;
+  res.bits = 1u + (uint32_t)act;
+#else
+  const StepResult res = env_step_core(sw, board, g, N, ag, step_count, act, a.p.time_limit);
+#endif
+
+  if (!(res.last && a.p.auto_reset)) {
+    // The common case.  Every wave of a launch reaches this point at about the same time, and
+    // until the first of them stores, the HBM write path -- what bounds the launch -- is idle:
+    // the 10 KB observation goes out first, then the state, and the small outputs (reward,
+    // extras: ballots and a pass over the board) are computed while those stores drain.
+    write_observation(sw, board, g, N, b, ag, step_count, a.ts, res.bits);
+    store_state(sw, board, g, N, b, ag, step_count, key, a.out);
+    write_step_outcome(sw, res, a.p, N, b, a.ts);
+    write_extras(sw, board, g, N, b, ag, a.ts);
+  } else {
+    // the few waves that restart an episode have the longest path through this kernel and
+    // every wave of the launch started together: let them go first wherever they compete
+    __builtin_amdgcn_s_setprio(3);
+    write_step_outcome(sw, res, a.p, N, b, a.ts);
+    write_extras(sw, board, g, N, b, ag, a.ts);  // of the terminal state
+    // VmapAutoResetWrapper._auto_reset: key, _ = split(state.key); state, ts = reset(key);
+    // only the observation of the terminal timestep is replaced.
+    // With a stash the new episode's State was generated ahead of time (stash_refill_kernel)
+    // and is only copied here; the entry is valid iff it was generated for exactly this
+    // episode's key and the refill that wrote it is known to have completed (ready_at: ordered
+    // by the host through the stream, never through in-kernel flags).
+    const int row = pf.row >= 0 ? pf.row
+                                : stash_probe_row(a.stash, probe, a.B, b, lane, key, a.tick);
+    if (pf.row >= 0) {
+      stash_row_commit(sw, board, g, pf, ag, key);
+      if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
+    } else if (row >= 0) {
+      load_state(sw, board, g, N, row, a.stash.next, ag, step_count, key);
+      if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
+    } else {
+      Key2 rk, unused;
+      split2_lanes(sw, key, rk, unused);
+      key = regenerate(sw, board, W, g, N, rk, ag);
+    }
+    step_count = 0;
+    request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+    const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
+    store_state(sw, board, g, N, b, ag, step_count, key, a.out);
+    write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
+  }
+#if defined(RBG_PROBE_STEP_TIMES)
+  // wave start / end (10 ns ticks) and where it ran, in place of three extras (probe builds only)
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores have left the wave
+  if (lane == 0) {
+    a.ts.num_connections[b] = (int32_t)probe_t0;
+    a.ts.total_path_length[b] = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();
+    a.ts.obs_step_count[b] = (int)(((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 16) |
+                                   (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu));
+  }
+#endif
+}
+
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_kernel(EnvArgs a) {
+  connector_body<kModeReset>(a);
+}
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_observe_kernel(EnvArgs a) {
+  connector_body<kModeObserve>(a);
+}
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_kernel(EnvArgs a) {
+  connector_body<kModeStep>(a);
+}
+
+
+// Producer of the stash: for every env whose entry is not the one its running episode will need
+// (tag != refill_key), generate G(split(refill_key)[0]) and publish it.  One env per sub-wave
+// (two per wave at 16x16/10); sub-waves with nothing to do retire at once.
+struct RefillArgs {
+  int B, N;
+  Geo g;
+  StashPtrs stash;
+};
+
+template <int LPB>
+__global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
+  constexpr int kSubs = SubWave<LPB>::kSubs;
+  const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = (blockIdx.x * kWavesPerBlock + wib) * kSubs + sw.h;
+  if (b >= a.B) return;
+  const uint2 want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
+  const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
+  if (want.x == have.x && want.y == have.y) return;  // nothing to do for this env
+  const Geo g = a.g;
+  uint32_t *board = g_lds + (wib * kSubs + sw.h) * slab_words<LPB>(g);
+  uint32_t *W = board + board_words(g);
+  AgentRegs ag = {0, 0, 0, 0, 0, 0};
+  Key2 key = {want.x, want.y}, rk, unused;
+  split2_lanes(sw, key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
+  const Key2 next_key = regenerate(sw, board, W, g, a.N, rk, ag);
+  store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
+  if (sw.l == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
+}
+
+}  // namespace

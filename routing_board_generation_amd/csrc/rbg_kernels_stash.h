@@ -1,0 +1,143 @@
+// rbg_kernels_stash.h -- the next-episode stash (include/rbg_prw.h::rbg_stash) on the device side:
+// lookup, early probes, row prefetch, refill requests.  Shared by the env kernels and the rollout.
+#pragma once
+#include "rbg_kernels_common.h"
+
+namespace {
+
+// Pre-generated next-episode states (include/rbg_prw.h::rbg_stash).  `next` of env b is the
+// State the auto-reset of an episode with State.key == tag[b] must produce.
+struct StashPtrs {
+  StatePtrs next;        // depth * B rows; slot s of env b = row s * B + b
+  uint32_t *tag;         // [depth*B][2]
+  int32_t *ready_at;     // [depth*B] first launch tick that may consume the row
+  uint32_t *refill_key;  // [depth*B][2] the State.key whose successor the row should hold next
+  int32_t *hits;         // [B] nullable diagnostics: resets served from the stash
+  int depth;             // 1 or 2
+};
+
+// Row of the stash that holds the successor of the episode with State.key `key`, or -1.
+__device__ __forceinline__ int stash_lookup(const StashPtrs &st, int B, int b, Key2 key,
+                                            int tick) {
+  int row = -1;
+  if (st.tag) {
+    for (int s = 0; s < st.depth; ++s) {
+      const int r = s * B + b;
+      const uint2 tag = *reinterpret_cast<const uint2 *>(&st.tag[2 * (size_t)r]);
+      if (tick >= st.ready_at[r] && tag.x == key.a && tag.y == key.b) row = r;
+    }
+  }
+  return row;
+}
+
+// The same lookup with its loads issued early: lane s < depth fetches (tag, ready_at) of row
+// s * B + b when the wave starts, so that an env that ends its episode a microsecond later finds
+// the answer in registers instead of starting two dependent global loads on the launch's tail.
+struct StashProbe {
+  uint2 tag;
+  int ready_at;
+};
+__device__ __forceinline__ StashProbe stash_probe_issue(const StashPtrs &st, int B, int b,
+                                                        int lane) {
+  StashProbe p = {make_uint2(0u, 0u), 0x7FFFFFFF};
+  if (st.tag && lane < st.depth) {
+    const int r = lane * B + b;
+    p.tag = *reinterpret_cast<const uint2 *>(&st.tag[2 * (size_t)r]);
+    p.ready_at = st.ready_at[r];
+  }
+  return p;
+}
+__device__ __forceinline__ int stash_probe_row(const StashPtrs &st, const StashProbe &p, int B,
+                                               int b, int lane, Key2 key, int tick) {
+  const bool ok = st.tag && lane < st.depth && tick >= p.ready_at && p.tag.x == key.a &&
+                  p.tag.y == key.b;
+  const uint64_t m = __ballot(ok) & 3ull;  // depth <= 2; the later slot wins, as in stash_lookup
+  return m == 0ull ? -1 : (m & 2ull ? B + b : b);
+}
+
+// An episode that ends on the time limit is known to end as soon as step_count is loaded: its
+// wave fetches the stash row while it steps (registers only; one dwordx4 per lane covers grids
+// up to 16x16) and finds the next episode's State ready when it gets there.  Other terminations
+// (every agent connected or blocked) take the plain load_state path.
+struct RowPrefetch {
+  int row;  // -1: nothing prefetched
+  int4 grid;
+  int2 s, t, p;
+  uint2 key;
+};
+__device__ __forceinline__ RowPrefetch stash_row_issue(const StatePtrs &next, const Geo &g, int N,
+                                                       int row, int lane) {
+  RowPrefetch pf;
+  pf.row = row;
+  pf.grid = make_int4(0, 0, 0, 0);
+  pf.s = pf.t = pf.p = make_int2(0, 0);
+  pf.key = make_uint2(0u, 0u);
+  if (row >= 0) {
+    if (lane * 4 < g.n)
+      pf.grid = *reinterpret_cast<const int4 *>(&next.grid[(size_t)row * g.n + lane * 4]);
+    if (lane < N) {
+      const size_t o = ((size_t)row * N + lane) * 2;
+      pf.s = *reinterpret_cast<const int2 *>(&next.start[o]);
+      pf.t = *reinterpret_cast<const int2 *>(&next.target[o]);
+      pf.p = *reinterpret_cast<const int2 *>(&next.position[o]);
+    }
+    pf.key = *reinterpret_cast<const uint2 *>(&next.key[2 * (size_t)row]);
+  }
+  return pf;
+}
+__device__ __forceinline__ void stash_row_commit(const SubWave<64> &sw, uint32_t *board,
+                                                 const Geo &g, const RowPrefetch &pf,
+                                                 AgentRegs &ag, Key2 &key) {
+  const int lane = sw.l;
+  for (int w = lane; w < g.words; w += kWaveSize) board[w] = kWall;
+  wave_lds_fence();
+  if (lane * 4 < g.n) {
+    const int r = div_m(g, lane * 4);
+    *reinterpret_cast<uint4 *>(&board[pad_index(g, r, lane * 4 - r * g.m)]) =
+        make_uint4((uint32_t)pf.grid.x, (uint32_t)pf.grid.y, (uint32_t)pf.grid.z,
+                   (uint32_t)pf.grid.w);
+  }
+  wave_lds_fence();
+  ag.r0 = pf.s.x; ag.c0 = pf.s.y; ag.tr = pf.t.x; ag.tc = pf.t.y; ag.r = pf.p.x; ag.c = pf.p.y;
+  key.a = pf.key.x;
+  key.b = pf.key.y;
+}
+
+// After a (re)start with State.key `key`: ask the next refill for what comes after it
+// (include/rbg_prw.h::rbg_stash).  depth 1: the env's one row is requested for `key`.  depth 2:
+// one row is reserved for `key` unless one already is, and the other -- just consumed, or never
+// used -- is requested for the key of the episode after the next, split(split(key)[0])[0]
+// (VmapAutoResetWrapper's split, then the generator's).  Called by the whole sub-wave.
+template <int LPB>
+__device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const StashPtrs &st, int B,
+                                               int b, Key2 key, int ready_at) {
+  if (!st.refill_key) return;
+  if (st.depth == 1) {
+    if (sw.l == 0) {
+      *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)b]) = make_uint2(key.a, key.b);
+      st.ready_at[b] = ready_at;
+    }
+    return;
+  }
+  Key2 rk, after, unused;
+  split2_lanes(sw, key, rk, unused);
+  split2_lanes(sw, rk, after, unused);
+  if (sw.l == 0) {
+    const int r0 = b, r1 = B + b;
+    const uint2 k0 = *reinterpret_cast<const uint2 *>(&st.refill_key[2 * (size_t)r0]);
+    const uint2 k1 = *reinterpret_cast<const uint2 *>(&st.refill_key[2 * (size_t)r1]);
+    int other = r1;
+    if (k0.x == key.a && k0.y == key.b) {
+      other = r1;
+    } else if (k1.x == key.a && k1.y == key.b) {
+      other = r0;
+    } else {
+      *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)r0]) = make_uint2(key.a, key.b);
+      st.ready_at[r0] = ready_at;
+    }
+    *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)other]) = make_uint2(after.a, after.b);
+    st.ready_at[other] = ready_at;
+  }
+}
+
+}  // namespace
