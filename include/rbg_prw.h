@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 7
+#define RBG_ABI_VERSION 8
 
 #define RBG_E_NULL (-1)   /* a required pointer is NULL */
 #define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
@@ -369,6 +369,71 @@ int rbg_connector_rollout_record(int B, int m, int N, const rbg_state *state_in,
                                  const rbg_timestep *trajectory, int32_t *trajectory_action,
                                  const rbg_stash *stash, int tick, int ready_delay,
                                  void *stream);
+
+/* ---- the coupled env hot path for EVERY generator -------------------------------------------
+ * The reference couples any `Generator` to `Connector` under VmapAutoResetWrapper
+ * (routing_board_generation/rl_training/setup_train.py:112-161: generation_type offline_seed_extension,
+ * offline_parallel_rw, online_uniform, online_seq_rw, online_random_seed, online_parallel_rw).
+ * rbg_generator names the generator whose `__call__(key)` (re)starts episodes inside the env
+ * launches below; NULL = ParallelRandomWalkGenerator (the calls above).  All of them start with
+ * `key, _ = split(key)` and store that child as State.key, which is what the stash protocol needs.
+ *   RBG_GEN_PARALLEL_RW     rl_training/online_generators/parallel_random_walk_generator.py:46-77
+ *   RBG_GEN_UNIFORM         rl_training/online_generators/uniform_generator.py:70-109
+ *   RBG_GEN_SEQUENTIAL_RW   rl_training/online_generators/sequential_random_walk_generator.py:34-66
+ *   RBG_GEN_SEED_EXTENSION  rl_training/online_generators/random_seed_generator.py:28-57 with
+ *                           randomness / two_sided / extension_iterations / max_extension_steps as in
+ *                           rbg_seed_extension_generate (the generator's defaults: 0, 1, 1, INT32_MAX)
+ *   RBG_GEN_DATASET         rl_training/offline_generation/dataset_generator_jax.py:112-141:
+ *                           sample one of n_boards stored boards, heads / targets int32
+ *                           [n_boards][N][2] (agent-major, device memory that outlives the launches) */
+#define RBG_GEN_PARALLEL_RW 0
+#define RBG_GEN_UNIFORM 1
+#define RBG_GEN_SEQUENTIAL_RW 2
+#define RBG_GEN_SEED_EXTENSION 3
+#define RBG_GEN_DATASET 4
+
+typedef struct rbg_generator {
+  int32_t kind;                 /* RBG_GEN_* */
+  float randomness;             /* SEED_EXTENSION */
+  int32_t two_sided;            /* SEED_EXTENSION */
+  int32_t extension_iterations; /* SEED_EXTENSION, >= 0 */
+  int32_t max_extension_steps;  /* SEED_EXTENSION */
+  int32_t n_boards;             /* DATASET */
+  const int32_t *heads;         /* DATASET */
+  const int32_t *targets;       /* DATASET */
+} rbg_generator;
+
+/* vmap(Connector(generator).reset)(keys); stash may be NULL (then tick / ready_delay are unused). */
+int rbg_connector_reset_gen(const rbg_generator *generator, const uint32_t *keys, int B, int m,
+                            int N, const rbg_state *state, const rbg_timestep *timestep,
+                            const rbg_stash *stash, int tick, int ready_delay, void *stream);
+
+/* VmapAutoResetWrapper(Connector(generator)).step: rbg_connector_step_prefetch for any generator.
+ * A finished episode takes its successor from the stash when a matching row is ready; otherwise
+ * the generator runs inline in that env's wavefront (same result, a longer launch), so the
+ * reference's "regenerate every env on every step" (vmap(lax.cond)) never happens.
+ * policy_keys (nullable): non-NULL = the action comes from the rbg_random_actions policy of global
+ * step policy_t inside the launch (action may then be NULL). */
+int rbg_connector_step_gen(const rbg_generator *generator, int B, int m, int N,
+                           const rbg_state *state_in, const rbg_state *state_out,
+                           const int32_t *action, const uint32_t *policy_keys, uint32_t policy_t,
+                           const rbg_env_params *params, const rbg_timestep *timestep,
+                           const rbg_stash *stash, int tick, int ready_delay, void *stream);
+
+/* rbg_stash_refill with the generator's own producer: next[r] = generator(split(refill_key[r])[0])
+ * for every row with tag[r] != refill_key[r]. */
+int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
+                         const rbg_stash *stash, void *stream);
+
+/* rbg_connector_rollout_record for any generator (the random-agent benchmark runs on whatever
+ * generator the config names: benchmarking/benchmarks/benchmark_on_random_agent.py:59-102). */
+int rbg_connector_rollout_gen(const rbg_generator *generator, int B, int m, int N,
+                              const rbg_state *state_in, const rbg_state *state_out,
+                              const uint32_t *policy_keys, uint32_t t0, int n_steps,
+                              const rbg_env_params *params, const rbg_rollout_stats *stats,
+                              const rbg_timestep *last_timestep, const rbg_timestep *trajectory,
+                              int32_t *trajectory_action, const rbg_stash *stash, int tick,
+                              int ready_delay, void *stream);
 
 
 #ifdef __cplusplus

@@ -14,13 +14,17 @@ LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
 HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 # -amdgpu-sched-strategy=max-ilp: the walk's straggler boards run one wave per SIMD, where an
 # instruction that depends on its predecessor issues after ~8 cycles and an independent one after
 # ~4 (tools/microbench/dep_latency.hip); the default scheduler (occupancy-first) leaves the
 # availability compares and the Threefry rounds as dependent runs (35.3 -> 31.7 us)
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
-               "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# (an internal LLVM option: OPTIONAL_FLAGS are dropped, with a warning, by a hipcc that rejects
+# them -- they change scheduling, never results; -ffp-contract=off is mandatory)
+REQUIRED_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-ffp-contract=off",
+                  "-std=c++17"]
+OPTIONAL_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+HIPCC_FLAGS = REQUIRED_FLAGS + OPTIONAL_FLAGS
 
 
 class NativeLibraryError(RuntimeError):
@@ -49,6 +53,16 @@ class RolloutStats(C.Structure):
 class Stash(C.Structure):
     _fields_ = [("next", State), ("tag", C.c_void_p), ("ready_at", C.c_void_p),
                 ("refill_key", C.c_void_p), ("hits", C.c_void_p), ("depth", C.c_int32)]
+
+
+class Generator(C.Structure):
+    """include/rbg_prw.h::rbg_generator"""
+    _fields_ = [("kind", C.c_int32), ("randomness", C.c_float), ("two_sided", C.c_int32),
+                ("extension_iterations", C.c_int32), ("max_extension_steps", C.c_int32),
+                ("n_boards", C.c_int32), ("heads", C.c_void_p), ("targets", C.c_void_p)]
+
+
+GEN_PARALLEL_RW, GEN_UNIFORM, GEN_SEQUENTIAL_RW, GEN_SEED_EXTENSION, GEN_DATASET = range(5)
 
 
 class EnvParams(C.Structure):
@@ -111,6 +125,22 @@ SIGNATURES = {
                                                C.POINTER(Timestep), C.POINTER(Timestep),
                                                C.c_void_p, C.POINTER(Stash), C.c_int, C.c_int,
                                                C.c_void_p]),
+    "rbg_connector_reset_gen": (C.c_int, [C.POINTER(Generator), C.c_void_p, C.c_int, C.c_int,
+                                          C.c_int, C.POINTER(State), C.POINTER(Timestep),
+                                          C.POINTER(Stash), C.c_int, C.c_int, C.c_void_p]),
+    "rbg_connector_step_gen": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(State), C.POINTER(State), C.c_void_p,
+                                         C.c_void_p, C.c_uint32, C.POINTER(EnvParams),
+                                         C.POINTER(Timestep), C.POINTER(Stash), C.c_int, C.c_int,
+                                         C.c_void_p]),
+    "rbg_stash_refill_gen": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(Stash), C.c_void_p]),
+    "rbg_connector_rollout_gen": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(State), C.POINTER(State), C.c_void_p,
+                                            C.c_uint32, C.c_int, C.POINTER(EnvParams),
+                                            C.POINTER(RolloutStats), C.POINTER(Timestep),
+                                            C.POINTER(Timestep), C.c_void_p, C.POINTER(Stash),
+                                            C.c_int, C.c_int, C.c_void_p]),
     "rbg_random_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "rbg_prw_initialise_agents": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] +
@@ -123,6 +153,24 @@ SIGNATURES = {
 }
 
 
+def hipcc_compile(extra_args, flags=None) -> None:
+    """hipcc with HIPCC_FLAGS (or `flags`) + extra_args; if that fails and OPTIONAL_FLAGS were in
+    it, once more without them (a scheduling preference must not break the build)."""
+    import warnings
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = list(HIPCC_FLAGS if flags is None else flags)
+    try:
+        subprocess.check_call([hipcc] + flags + list(extra_args))
+    except subprocess.CalledProcessError:
+        plain = [f for f in flags if f not in OPTIONAL_FLAGS]
+        if plain == flags:
+            raise
+        warnings.warn(f"hipcc failed with {OPTIONAL_FLAGS}; building without them "
+                      "(same results, the walk launch is ~10 % slower)")
+        subprocess.check_call([hipcc] + plain + list(extra_args))
+
+
 def build_native(force: bool = False) -> str:
     """Compile csrc/prw_kernels.hip for gfx950 into lib/librbg_prw.so (hipcc cross-compiles
     without a GPU)."""
@@ -132,8 +180,7 @@ def build_native(force: bool = False) -> str:
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in sources))
     if force or stale:
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.check_call([hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC_PATH])
+        hipcc_compile(["-o", LIB_PATH, SRC_PATH])
     return LIB_PATH
 
 

@@ -18,7 +18,6 @@ from typing import Optional, Tuple
 import torch
 
 from .. import ops, specs
-from ..online_generators.parallel_random_walk_generator import ParallelRandomWalkGenerator
 from ..online_generators.uniform_generator import Generator, UniformRandomGenerator
 from ..types import Agent, Observation, State, TimeStep
 
@@ -97,6 +96,10 @@ class Connector:
         self._aggregate = False  # switched on by MultiToSingleWrapper
         self._sessions = {}  # (B, device, wrapper + env parameters) -> ops.ConnectorSession
         self._rollout_epochs = {}  # (B, device) -> ops.EpochStash of random_rollout
+        # the generator as the env launches run it (include/rbg_prw.h::rbg_generator); None for a
+        # user-defined Python generator, which takes the generic path (_generic_auto_reset)
+        spec = getattr(self._generator, "native_spec", None)
+        self._gen = spec() if callable(spec) else None
 
     @property
     def unwrapped(self) -> "Connector":
@@ -109,7 +112,7 @@ class Connector:
     def _session(self, B: int, device: torch.device) -> ops.ConnectorSession:
         """The launch context of batched reset/step calls (ops.ConnectorSession), one per batch
         size / device / wrapper configuration."""
-        fused_reset = self._auto_reset and isinstance(self._generator, ParallelRandomWalkGenerator)
+        fused_reset = self._auto_reset and self._gen is not None
         k = (B, device, fused_reset, self._prefetch_delay, self._donate, self._aggregate,
              self.time_limit,
              self._reward_fn.timestep_reward, self._reward_fn.connected_reward)
@@ -121,7 +124,7 @@ class Connector:
                 B, self.grid_size, self.num_agents, device, self.time_limit,
                 self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
                 auto_reset=fused_reset, refill_every=self._prefetch_delay, donate=self._donate,
-                aggregate=self._aggregate)
+                aggregate=self._aggregate, gen=self._gen)
         return sess
 
     # ---------------------------------------------------------------------------------- specs
@@ -150,13 +153,13 @@ class Connector:
     def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
         batched = key.dim() == 2
         keys = (key if batched else key[None]).contiguous()
-        if isinstance(self._generator, ParallelRandomWalkGenerator):
-            # fused: walk + State + observation in one launch
+        if self._gen is not None:
+            # fused: generator + State + observation in one launch
             if batched:
                 sess = self._session(keys.shape[0], keys.device)
                 st, ts = sess.reset(keys)
                 return _state_from_leaves(st, sess.agent_ids), _timestep_from_leaves(ts)
-            st, ts = ops.connector_reset(keys, self.grid_size, self.num_agents)
+            st, ts = ops.connector_reset(keys, self.grid_size, self.num_agents, gen=self._gen)
         else:
             st = _state_bufs(self._generator(keys), True)
             ts = ops.connector_observe(st)
@@ -165,7 +168,7 @@ class Connector:
     # ---------------------------------------------------------------------------------- step
     def step(self, state: State, action: torch.Tensor) -> Tuple[State, TimeStep]:
         batched = state.grid.dim() == 3
-        fused_reset = self._auto_reset and isinstance(self._generator, ParallelRandomWalkGenerator)
+        fused_reset = self._auto_reset and self._gen is not None
         if batched and (fused_reset or not self._auto_reset):
             # next-episode States come from the session's stash when it holds them (same results
             # either way)
@@ -179,7 +182,8 @@ class Connector:
         st = _state_bufs(state, batched)
         act = (action if batched else action[None]).to(torch.int32).contiguous()
         so, ts = ops.connector_step(st, act, self.time_limit, self._reward_fn.timestep_reward,
-                                    self._reward_fn.connected_reward, auto_reset=fused_reset)
+                                    self._reward_fn.connected_reward, auto_reset=fused_reset,
+                                    gen=self._gen)
         if self._auto_reset and not fused_reset:
             so, ts = self._generic_auto_reset(so, ts)
         return _make_state(so, batched), self._single_agent_view(_make_timestep(ts, batched))
@@ -203,8 +207,10 @@ class Connector:
         `step(state, action)` of the loop returns (what `lax.scan` stacks in run_epoch)."""
         if state.grid.dim() != 3:
             raise ValueError("random_rollout expects a batched state")
-        if self._auto_reset and not isinstance(self._generator, ParallelRandomWalkGenerator):
-            raise NotImplementedError("fused rollouts need the ParallelRandomWalkGenerator")
+        if self._auto_reset and self._gen is None:
+            raise NotImplementedError(
+                "fused rollouts need a generator the launch can run itself (Generator.native_spec); "
+                "a user-defined Python generator steps through Connector.step")
         epochs = None
         if self._auto_reset and self._prefetch_delay > 0:
             # two-slot next-episode stash, refilled after every launch: also an env that finishes
@@ -214,22 +220,26 @@ class Connector:
             if epochs is None:
                 self._rollout_epochs.clear()
                 epochs = self._rollout_epochs[(B, dev)] = ops.EpochStash(
-                    B, self.grid_size, self.num_agents, dev, every=1, serial=True, depth=2)
+                    B, self.grid_size, self.num_agents, dev, every=1, serial=True, depth=2,
+                    gen=self._gen)
         if record:
             so, _, traj = ops.connector_rollout_record(
                 _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
                 self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
-                auto_reset=self._auto_reset, epochs=epochs)
+                auto_reset=self._auto_reset, epochs=epochs, gen=self._gen)
             return _make_state(so, True), traj["action"], _make_timestep(traj, True)
         so, stats, ts = ops.connector_rollout(
             _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
             self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
-            auto_reset=self._auto_reset, want_timestep=want_timestep, epochs=epochs)
+            auto_reset=self._auto_reset, want_timestep=want_timestep, epochs=epochs,
+            gen=self._gen)
         return _make_state(so, True), stats, (_make_timestep(ts, True) if ts is not None else None)
 
     def _generic_auto_reset(self, so, ts):
-        """VmapAutoResetWrapper for generators without a fused kernel: regenerate every env from
-        split(state.key)[0] and select where the timestep is LAST (what vmap(lax.cond) does)."""
+        """VmapAutoResetWrapper for a user-defined Python generator (Generator.native_spec() is
+        None): regenerate every env from split(state.key)[0] and select where the timestep is
+        LAST -- what vmap(lax.cond) does in the reference for every generator.  The generators
+        this package ships never come here."""
         from ..random import split
 
         done = ts["step_type"] == 2

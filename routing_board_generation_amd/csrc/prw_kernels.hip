@@ -109,6 +109,76 @@ bool state_complete(const rbg_state *s) {
   return s && s->grid && s->step_count && s->start && s->target && s->position && s->key;
 }
 
+// rbg_generator -> the device-side description of the env's generator (rbg_regen.h) + the count of
+// its start-cell shuffle prefix (make_geo's threshold).  NULL = ParallelRandomWalk.
+int fill_gen(const rbg_generator *gen, int m, int N, GenSpec *gs, int *prefix_count,
+             const char *who) {
+  memset(gs, 0, sizeof(*gs));
+  *prefix_count = N;
+  if (!gen || gen->kind == RBG_GEN_PARALLEL_RW) return 0;
+  gs->kind = gen->kind;
+  const int words = (m + 4) * (m + 4);
+  switch (gen->kind) {
+    case RBG_GEN_UNIFORM:
+      if (2 * N > m * m) return fail(RBG_E_SHAPE, "uniform generator: 2N exceeds m*m cells");
+      *prefix_count = 2 * N;
+      return 0;
+    case RBG_GEN_SEQUENTIAL_RW:
+      if (m < 3) return fail(RBG_E_SHAPE, "sequential random walk: m must be >= 3");
+      return 0;
+    case RBG_GEN_SEED_EXTENSION: {
+      if (N > (m / 2) * (m / 2))
+        return fail(RBG_E_SHAPE, "seed extension: N exceeds the (m/2)^2 seed cells");
+      if (gen->extension_iterations < 0 || gen->max_extension_steps < 0)
+        return fail(RBG_E_PARAM, "seed extension: bad iteration / step count");
+      SeParams &p = gs->se;
+      p.N = N;
+      p.iterations = gen->extension_iterations;
+      p.seed_only = 0;
+      p.max_steps = gen->max_extension_steps;
+      p.two_sided = gen->two_sided != 0;
+      p.randomness = gen->randomness;
+      p.rnd_mode = !(gen->randomness > 0.0f) ? 0 : (gen->randomness >= 1.0f ? 1 : 2);
+      p.bfs_last = 0;  // a State never shows the last re-routing
+      p.half = m / 2;
+      gs->extra_words = se_extra_words(words, m * m);
+      return 0;
+    }
+    case RBG_GEN_DATASET: {
+      if (gen->n_boards < 1) return fail(RBG_E_SHAPE, "dataset generator: n_boards < 1");
+      if (!gen->heads || !gen->targets) return fail(RBG_E_NULL, "dataset generator: NULL boards");
+      gs->ds_heads = gen->heads;
+      gs->ds_targets = gen->targets;
+      gs->ds_span = (uint32_t)gen->n_boards;
+      const uint32_t m16 = 65536u % gs->ds_span;
+      gs->ds_mult = (uint32_t)(m16 * m16) % gs->ds_span;  // wrapping uint32, as jax's _randint
+      return 0;
+    }
+    default:
+      snprintf(g_err, sizeof(g_err), "%s: unknown generator kind %d", who, gen->kind);
+      return RBG_E_PARAM;
+  }
+}
+
+template <int KIND>
+void launch_env_gen(const EnvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  if (a.mode == kModeReset) {
+    hipLaunchKernelGGL(connector_reset_gen_kernel<KIND>, grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL(connector_step_gen_kernel<KIND>, grid, block, lds, st, a);
+  }
+}
+
+template <int KIND>
+void launch_rollout_gen(const RolloutArgs &a, bool record, dim3 grid, size_t lds,
+                               hipStream_t st) {
+  if (record) {
+    hipLaunchKernelGGL((connector_rollout_gen_kernel<KIND, true>), grid, dim3(kBlock), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((connector_rollout_gen_kernel<KIND, false>), grid, dim3(kBlock), lds, st, a);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -307,12 +377,21 @@ int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *tra
 static int launch_env(EnvArgs &a, void *stream, const char *what) {
   const dim3 grid((a.B + kEnvWavesPerBlock - 1) / kEnvWavesPerBlock),
       block(kWaveSize * kEnvWavesPerBlock);
-  const size_t lds = lds_bytes(a.g) / kWavesPerBlock * kEnvWavesPerBlock;
+  const size_t lds = lds_bytes(a.g) / kWavesPerBlock * kEnvWavesPerBlock +
+                     (size_t)kEnvWavesPerBlock * (size_t)a.gen.extra_words * sizeof(uint32_t);
   hipStream_t st = (hipStream_t)stream;
-  if (a.mode == kModeReset) {
-    hipLaunchKernelGGL(connector_reset_kernel, grid, block, lds, st, a);
-  } else if (a.mode == kModeObserve) {
+  if (a.mode == kModeObserve) {
     hipLaunchKernelGGL(connector_observe_kernel, grid, block, lds, st, a);
+  } else if (a.gen.kind == kGenUniform) {
+    launch_env_gen<kGenUniform>(a, grid, block, lds, st);
+  } else if (a.gen.kind == kGenSeqRw) {
+    launch_env_gen<kGenSeqRw>(a, grid, block, lds, st);
+  } else if (a.gen.kind == kGenSeedExt) {
+    launch_env_gen<kGenSeedExt>(a, grid, block, lds, st);
+  } else if (a.gen.kind == kGenDataset) {
+    launch_env_gen<kGenDataset>(a, grid, block, lds, st);
+  } else if (a.mode == kModeReset) {
+    hipLaunchKernelGGL(connector_reset_kernel, grid, block, lds, st, a);
   } else {
     hipLaunchKernelGGL(connector_step_kernel, grid, block, lds, st, a);
   }
@@ -321,17 +400,7 @@ static int launch_env(EnvArgs &a, void *stream, const char *what) {
 
 int rbg_connector_reset(const uint32_t *keys, int B, int m, int N, const rbg_state *state,
                         const rbg_timestep *timestep, void *stream) {
-  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_reset: B < 0");
-  EnvArgs a;
-  memset(&a, 0, sizeof(a));
-  if (int rc = make_geo(m, N, &a.g)) return rc;
-  if (B == 0) return 0;
-  if (!keys || !timestep) return fail(RBG_E_NULL, "rbg_connector_reset: NULL pointer");
-  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_connector_reset: incomplete state");
-  if (int rc = check_align(a.g, state->grid, timestep->obs_grid, nullptr)) return rc;
-  a.keys = keys; a.B = B; a.N = N; a.out = to_ptrs(state); a.in = a.out;
-  a.ts = to_ptrs(timestep); a.mode = 0;
-  return launch_env(a, stream, "rbg_connector_reset");
+  return rbg_connector_reset_gen(nullptr, keys, B, m, N, state, timestep, nullptr, 0, 0, stream);
 }
 
 static int fill_stash(const rbg_stash *stash, StashPtrs *out, const char *who) {
@@ -356,61 +425,128 @@ static int fill_stash(const rbg_stash *stash, StashPtrs *out, const char *who) {
 int rbg_connector_reset_prefetch(const uint32_t *keys, int B, int m, int N, const rbg_state *state,
                                  const rbg_timestep *timestep, const rbg_stash *stash, int tick,
                                  int ready_delay, void *stream) {
-  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_reset_prefetch: B < 0");
+  return rbg_connector_reset_gen(nullptr, keys, B, m, N, state, timestep, stash, tick, ready_delay,
+                                 stream);
+}
+
+int rbg_connector_reset_gen(const rbg_generator *generator, const uint32_t *keys, int B, int m,
+                            int N, const rbg_state *state, const rbg_timestep *timestep,
+                            const rbg_stash *stash, int tick, int ready_delay, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_reset: B < 0");
   EnvArgs a;
   memset(&a, 0, sizeof(a));
   if (int rc = make_geo(m, N, &a.g)) return rc;
+  int prefix = N;
+  if (int rc = fill_gen(generator, m, N, &a.gen, &prefix, "rbg_connector_reset")) return rc;
+  if (int rc = make_geo(m, N, &a.g, prefix)) return rc;
   if (B == 0) return 0;
-  if (!keys || !timestep) return fail(RBG_E_NULL, "rbg_connector_reset_prefetch: NULL pointer");
-  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_connector_reset_prefetch: incomplete state");
+  if (!keys || !timestep) return fail(RBG_E_NULL, "rbg_connector_reset: NULL pointer");
+  if (!state_complete(state)) return fail(RBG_E_NULL, "rbg_connector_reset: incomplete state");
   if (int rc = check_align(a.g, state->grid, timestep->obs_grid, stash ? stash->next.grid : nullptr))
     return rc;
-  if (int rc = fill_stash(stash, &a.stash, "rbg_connector_reset_prefetch")) return rc;
+  if (int rc = fill_stash(stash, &a.stash, "rbg_connector_reset")) return rc;
   a.keys = keys; a.B = B; a.N = N; a.out = to_ptrs(state); a.in = a.out;
-  a.ts = to_ptrs(timestep); a.mode = 0; a.tick = tick; a.ready_delay = ready_delay;
-  return launch_env(a, stream, "rbg_connector_reset_prefetch");
+  a.ts = to_ptrs(timestep); a.mode = kModeReset; a.tick = tick; a.ready_delay = ready_delay;
+  return launch_env(a, stream, "rbg_connector_reset");
 }
 
 int rbg_connector_step_prefetch(int B, int m, int N, const rbg_state *state_in,
                                 const rbg_state *state_out, const int32_t *action,
                                 const rbg_env_params *params, const rbg_timestep *timestep,
                                 const rbg_stash *stash, int tick, int ready_delay, void *stream) {
-  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_step_prefetch: B < 0");
-  if (!params) return fail(RBG_E_NULL, "rbg_connector_step_prefetch: NULL params");
-  if (params->time_limit < 1) return fail(RBG_E_PARAM, "rbg_connector_step_prefetch: time_limit < 1");
+  return rbg_connector_step_gen(nullptr, B, m, N, state_in, state_out, action, nullptr, 0u, params,
+                                timestep, stash, tick, ready_delay, stream);
+}
+
+int rbg_connector_step_gen(const rbg_generator *generator, int B, int m, int N,
+                           const rbg_state *state_in, const rbg_state *state_out,
+                           const int32_t *action, const uint32_t *policy_keys, uint32_t policy_t,
+                           const rbg_env_params *params, const rbg_timestep *timestep,
+                           const rbg_stash *stash, int tick, int ready_delay, void *stream) {
+  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_step: B < 0");
+  if (!params) return fail(RBG_E_NULL, "rbg_connector_step: NULL params");
+  if (params->time_limit < 1) return fail(RBG_E_PARAM, "rbg_connector_step: time_limit < 1");
   EnvArgs a;
   memset(&a, 0, sizeof(a));
   if (int rc = make_geo(m, N, &a.g)) return rc;
+  int prefix = N;
+  if (int rc = fill_gen(generator, m, N, &a.gen, &prefix, "rbg_connector_step")) return rc;
+  if (int rc = make_geo(m, N, &a.g, prefix)) return rc;
   if (B == 0) return 0;
-  if (!action || !timestep) return fail(RBG_E_NULL, "rbg_connector_step_prefetch: NULL pointer");
+  if ((!action && !policy_keys) || !timestep)
+    return fail(RBG_E_NULL, "rbg_connector_step: NULL pointer");
   if (!state_complete(state_in) || !state_complete(state_out))
-    return fail(RBG_E_NULL, "rbg_connector_step_prefetch: incomplete state");
+    return fail(RBG_E_NULL, "rbg_connector_step: incomplete state");
   if (int rc = check_align(a.g, state_in->grid, state_out->grid, timestep->obs_grid)) return rc;
   if (stash)
     if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
-  if (int rc = fill_stash(stash, &a.stash, "rbg_connector_step_prefetch")) return rc;
+  if (int rc = fill_stash(stash, &a.stash, "rbg_connector_step")) return rc;
   a.B = B; a.N = N; a.in = to_ptrs(state_in); a.out = to_ptrs(state_out); a.action = action;
-  a.p = *params; a.ts = to_ptrs(timestep); a.mode = 2; a.tick = tick; a.ready_delay = ready_delay;
-  return launch_env(a, stream, "rbg_connector_step_prefetch");
+  a.policy_keys = policy_keys; a.policy_t = policy_t;
+  a.p = *params; a.ts = to_ptrs(timestep); a.mode = kModeStep; a.tick = tick;
+  a.ready_delay = ready_delay;
+  return launch_env(a, stream, "rbg_connector_step");
 }
 
 int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream) {
+  return rbg_stash_refill_gen(nullptr, B, m, N, stash, stream);
+}
+
+int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
+                         const rbg_stash *stash, void *stream) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_stash_refill: B < 0");
   RefillArgs a;
   memset(&a, 0, sizeof(a));
-  const int lpb = (m >= 2 && m <= kMaxM && N >= 1 && N <= kMaxN) ? pick_lpb(m, N) : kWaveSize;
-  if (int rc = make_geo(m, N, &a.g, -1, lpb)) return rc;
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  int prefix = N;
+  if (int rc = fill_gen(generator, m, N, &a.gen, &prefix, "rbg_stash_refill")) return rc;
+  const int kind = a.gen.kind;
+  // lanes per board: the walk's pipeline width; one lane per wire for SeedExtension; a whole wave
+  // for the others
+  int lpb = kWaveSize, wpb = kWavesPerBlock;
+  if (kind == kGenPrw) {
+    lpb = pick_lpb(m, N);
+  } else if (kind == kGenSeedExt) {
+    lpb = 16;
+    while (lpb < N) lpb *= 2;
+  }
+  if (int rc = make_geo(m, N, &a.g, prefix, lpb)) return rc;
+  size_t lds = lds_bytes(a.g, lpb);
+  if (kind == kGenSeedExt) {  // as rbg_seed_extension_generate: fewer, fuller waves while LDS fits
+    for (;;) {
+      const size_t per_board = (size_t)((a.g.words + 3) & ~3) + (size_t)(4 * lpb) +
+                               (size_t)a.gen.extra_words;
+      lds = (size_t)wpb * (size_t)(kWaveSize / lpb) * per_board * sizeof(uint32_t);
+      if (lds <= 64u * 1024u) break;
+      if (lpb < kWaveSize) lpb *= 2; else if (wpb > 1) wpb /= 2; else break;
+    }
+    if (lds > 64u * 1024u) return fail(RBG_E_SHAPE, "rbg_stash_refill: board too large");
+    if (int rc = make_geo(m, N, &a.g, prefix, lpb)) return rc;
+  }
   if (B == 0) return 0;
   if (!stash) return fail(RBG_E_NULL, "rbg_stash_refill: NULL stash");
   if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_stash_refill")) return rc;
   a.B = B * stash->depth;  // the kernel works on rows
   a.N = N;
-  const int envs_per_block = kWavesPerBlock * (kWaveSize / lpb);
-  const dim3 grid((a.B + envs_per_block - 1) / envs_per_block), block(kBlock);
-  const size_t lds = lds_bytes(a.g, lpb);
+  const int envs_per_block = wpb * (kWaveSize / lpb);
+  const dim3 grid((a.B + envs_per_block - 1) / envs_per_block), block(kWaveSize * wpb);
   hipStream_t st = (hipStream_t)stream;
-  if (lpb == 16) {
+  if (kind == kGenUniform) {
+    hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenUniform>), grid, block, lds, st, a);
+  } else if (kind == kGenSeqRw) {
+    hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenSeqRw>), grid, block, lds, st, a);
+  } else if (kind == kGenDataset) {
+    hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenDataset>), grid, block, lds, st, a);
+  } else if (kind == kGenSeedExt) {
+    if (lpb == 16) {
+      hipLaunchKernelGGL((stash_refill_gen_kernel<16, kGenSeedExt>), grid, block, lds, st, a);
+    } else if (lpb == 32) {
+      hipLaunchKernelGGL((stash_refill_gen_kernel<32, kGenSeedExt>), grid, block, lds, st, a);
+    } else {
+      hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenSeedExt>), grid, block, lds, st, a);
+    }
+  } else if (lpb == 16) {
     hipLaunchKernelGGL(stash_refill_kernel<16>, grid, block, lds, st, a);
   } else if (lpb == 32) {
     hipLaunchKernelGGL(stash_refill_kernel<32>, grid, block, lds, st, a);
@@ -437,20 +573,8 @@ int rbg_connector_observe(int B, int m, int N, const rbg_state *state,
 int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg_state *state_out,
                        const int32_t *action, const rbg_env_params *params,
                        const rbg_timestep *timestep, void *stream) {
-  if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_step: B < 0");
-  if (!params) return fail(RBG_E_NULL, "rbg_connector_step: NULL params");
-  if (params->time_limit < 1) return fail(RBG_E_PARAM, "rbg_connector_step: time_limit < 1");
-  EnvArgs a;
-  memset(&a, 0, sizeof(a));
-  if (int rc = make_geo(m, N, &a.g)) return rc;
-  if (B == 0) return 0;
-  if (!action || !timestep) return fail(RBG_E_NULL, "rbg_connector_step: NULL pointer");
-  if (!state_complete(state_in) || !state_complete(state_out))
-    return fail(RBG_E_NULL, "rbg_connector_step: incomplete state");
-  if (int rc = check_align(a.g, state_in->grid, state_out->grid, timestep->obs_grid)) return rc;
-  a.B = B; a.N = N; a.in = to_ptrs(state_in); a.out = to_ptrs(state_out); a.action = action;
-  a.p = *params; a.ts = to_ptrs(timestep); a.mode = 2;
-  return launch_env(a, stream, "rbg_connector_step");
+  return rbg_connector_step_gen(nullptr, B, m, N, state_in, state_out, action, nullptr, 0u, params,
+                                timestep, nullptr, 0, 0, stream);
 }
 
 int rbg_connector_rollout(int B, int m, int N, const rbg_state *state_in,
@@ -481,14 +605,30 @@ int rbg_connector_rollout_record(int B, int m, int N, const rbg_state *state_in,
                                  const rbg_timestep *trajectory, int32_t *trajectory_action,
                                  const rbg_stash *stash, int tick, int ready_delay,
                                  void *stream) {
+  return rbg_connector_rollout_gen(nullptr, B, m, N, state_in, state_out, policy_keys, t0, n_steps,
+                                   params, stats, last_timestep, trajectory, trajectory_action,
+                                   stash, tick, ready_delay, stream);
+}
+
+int rbg_connector_rollout_gen(const rbg_generator *generator, int B, int m, int N,
+                              const rbg_state *state_in, const rbg_state *state_out,
+                              const uint32_t *policy_keys, uint32_t t0, int n_steps,
+                              const rbg_env_params *params, const rbg_rollout_stats *stats,
+                              const rbg_timestep *last_timestep, const rbg_timestep *trajectory,
+                              int32_t *trajectory_action, const rbg_stash *stash, int tick,
+                              int ready_delay, void *stream) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_connector_rollout: B < 0");
   if (n_steps < 1) return fail(RBG_E_PARAM, "rbg_connector_rollout: n_steps < 1");
   if (!params) return fail(RBG_E_NULL, "rbg_connector_rollout: NULL params");
   if (params->time_limit < 1) return fail(RBG_E_PARAM, "rbg_connector_rollout: time_limit < 1");
   RolloutArgs a;
   memset(&a, 0, sizeof(a));
-  const int lpb = (m >= 2 && m <= kMaxM && N >= 1 && N <= kMaxN) ? pick_lpb(m, N) : kWaveSize;
-  if (int rc = make_geo(m, N, &a.g, -1, lpb)) return rc;
+  if (int rc = make_geo(m, N, &a.g)) return rc;
+  int prefix = N;
+  if (int rc = fill_gen(generator, m, N, &a.gen, &prefix, "rbg_connector_rollout")) return rc;
+  const int kind = a.gen.kind;
+  const int lpb = kind == kGenPrw ? pick_lpb(m, N) : kWaveSize;
+  if (int rc = make_geo(m, N, &a.g, prefix, lpb)) return rc;
   if (B == 0) return 0;
   if (!policy_keys) return fail(RBG_E_NULL, "rbg_connector_rollout: NULL policy_keys");
   if (!state_complete(state_in) || !state_complete(state_out))
@@ -527,16 +667,24 @@ int rbg_connector_rollout_record(int B, int m, int N, const rbg_state *state_in,
     // kernel (one env per wave, 16 waves per CU in flight), not the LDS-resident rollout's
     EnvArgs e;
     memset(&e, 0, sizeof(e));
-    if (int rc = make_geo(m, N, &e.g)) return rc;  // (the shuffle threshold depends on the lane count)
+    if (int rc = make_geo(m, N, &e.g, prefix)) return rc;  // (the shuffle threshold depends on the lane count)
     e.B = B; e.N = N; e.in = a.in; e.out = a.out; e.p = a.p; e.ts = a.ts; e.mode = kModeStep;
     e.stash = a.stash; e.tick = tick; e.ready_delay = ready_delay;
-    e.policy_keys = policy_keys; e.policy_t = t0;
+    e.policy_keys = policy_keys; e.policy_t = t0; e.gen = a.gen;
     return launch_env(e, stream, "rbg_connector_rollout");
   }
   const int envs_per_block = kWavesPerBlock * (kWaveSize / lpb);
   const dim3 grid((B + envs_per_block - 1) / envs_per_block), block(kBlock);
-  const size_t lds = lds_bytes(a.g, lpb);
+  const size_t lds = lds_bytes(a.g, lpb) + (size_t)envs_per_block * (size_t)a.gen.extra_words *
+                                               sizeof(uint32_t);
   hipStream_t st = (hipStream_t)stream;
+  if (kind != kGenPrw) {
+    if (kind == kGenUniform) launch_rollout_gen<kGenUniform>(a, record, grid, lds, st);
+    else if (kind == kGenSeqRw) launch_rollout_gen<kGenSeqRw>(a, record, grid, lds, st);
+    else if (kind == kGenSeedExt) launch_rollout_gen<kGenSeedExt>(a, record, grid, lds, st);
+    else launch_rollout_gen<kGenDataset>(a, record, grid, lds, st);
+    return check_hip(hipGetLastError(), "rbg_connector_rollout");
+  }
   if (record) {
     return check_hip((hipError_t)launch_rollout_record(a, lpb, grid.x, lds, st),
                      "rbg_connector_rollout_record");

@@ -2,6 +2,7 @@
 // kernels) and the producer of the next-episode stash.
 #pragma once
 #include "rbg_kernels_stash.h"
+#include "rbg_regen.h"
 
 namespace {
 
@@ -19,6 +20,7 @@ struct EnvArgs {
   int tick, ready_delay;
   const uint32_t *policy_keys;  // step only: non-NULL = the action comes from the masked-uniform
   uint32_t policy_t;            // random policy (rbg_random_actions) of global step policy_t
+  GenSpec gen;  // the env's generator (rbg_regen.h); all zero = ParallelRandomWalk
 };
 
 #ifndef RBG_ENV_WPB
@@ -27,10 +29,12 @@ struct EnvArgs {
 constexpr int kEnvWavesPerBlock = RBG_ENV_WPB;  // waves (envs) per workgroup of the env kernels
 
 // One body, three kernels (reset / observe / step) so that every launch population has its own
-// name in a rocprofv3 kernel trace.
+// name in a rocprofv3 kernel trace.  KIND = the generator that (re)starts episodes
+// (rbg_regen.h): the ParallelRandomWalk kernels keep their round-1 names, the other generators
+// of setup_train.py:112-152 get connector_{reset,step}_gen_kernel<KIND>.
 enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
 
-template <int MODE>
+template <int MODE, int KIND>
 __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 #if defined(RBG_PROBE_STEP_TIMES)  // developer probe (tools/probe_step.py --times)
   const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
@@ -40,7 +44,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * kEnvWavesPerBlock + wib;
   if (b >= a.B) return;
-  uint32_t *board = g_lds + wib * slab_words<64>(a.g);
+  uint32_t *board = g_lds + wib * env_slab_words<64>(a.g, a.gen);
   uint32_t *W = board + board_words(a.g);
   const Geo g = a.g;
   const int N = a.N;
@@ -50,7 +54,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
     Key2 kin;
     kin.a = a.keys[2 * (size_t)b];
     kin.b = a.keys[2 * (size_t)b + 1];
-    const Key2 key = regenerate(sw, board, W, g, N, kin, ag);
+    const Key2 key = regenerate_kind<64, KIND>(sw, board, W, g, N, kin, ag, a.gen);
     store_state(sw, board, g, N, b, ag, 0, key, a.out);
     request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
     write_observation(sw, board, g, N, b, ag, 0, a.ts,
@@ -132,7 +136,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
     } else {
       Key2 rk, unused;
       split2_lanes(sw, key, rk, unused);
-      key = regenerate(sw, board, W, g, N, rk, ag);
+      key = regenerate_kind<64, KIND>(sw, board, W, g, N, rk, ag, a.gen);
     }
     step_count = 0;
     request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
@@ -153,13 +157,24 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 }
 
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_kernel(EnvArgs a) {
-  connector_body<kModeReset>(a);
+  connector_body<kModeReset, kGenPrw>(a);
 }
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_observe_kernel(EnvArgs a) {
-  connector_body<kModeObserve>(a);
+  connector_body<kModeObserve, kGenPrw>(a);
 }
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_kernel(EnvArgs a) {
-  connector_body<kModeStep>(a);
+  connector_body<kModeStep, kGenPrw>(a);
+}
+// Connector(generator = Uniform / SequentialRandomWalk / SeedExtension / offline dataset)
+template <int KIND>
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_gen_kernel(
+    EnvArgs a) {
+  connector_body<kModeReset, KIND>(a);
+}
+template <int KIND>
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_gen_kernel(
+    EnvArgs a) {
+  connector_body<kModeStep, KIND>(a);
 }
 
 
@@ -170,6 +185,7 @@ struct RefillArgs {
   int B, N;
   Geo g;
   StashPtrs stash;
+  GenSpec gen;
 };
 
 template <int LPB>
@@ -191,6 +207,43 @@ __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
   const Key2 next_key = regenerate(sw, board, W, g, a.N, rk, ag);
   store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
   if (sw.l == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
+}
+
+// The same producer for the other generators.  Their sub-waves run in lock-step (SeedExtension's
+// chain phase, one instruction stream for the boards of a wave), so a sub-wave whose row needs
+// nothing does not retire: it redoes the wave's first requested board and stores nothing; a wave
+// none of whose rows is requested retires at once.  blockDim.x / 64 waves per workgroup.
+template <int LPB, int KIND>
+__global__ __launch_bounds__(kBlock) void stash_refill_gen_kernel(RefillArgs a) {
+  constexpr int kSubs = SubWave<LPB>::kSubs;
+  const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpb = (int)(blockDim.x >> 6);
+  const int b = (blockIdx.x * wpb + wib) * kSubs + sw.h;
+  uint2 want = make_uint2(0u, 0u);
+  bool need = false;
+  if (b < a.B) {
+    want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
+    const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
+    need = want.x != have.x || want.y != have.y;
+  }
+  const uint64_t busy = __ballot(need);
+  if (busy == 0ull) return;  // wave-uniform
+  const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)busy) - 1);
+  Key2 key;
+  key.a = need ? want.x : (uint32_t)__builtin_amdgcn_readlane((int)want.x, src);
+  key.b = need ? want.y : (uint32_t)__builtin_amdgcn_readlane((int)want.y, src);
+  const Geo g = a.g;
+  uint32_t *board = g_lds + (wib * kSubs + sw.h) * env_slab_words<LPB>(g, a.gen);
+  uint32_t *W = board + board_words(g);
+  AgentRegs ag = {0, 0, 0, 0, 0, 0};
+  Key2 rk, unused;
+  split2_lanes(sw, key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
+  const Key2 next_key = regenerate_kind<LPB, KIND>(sw, board, W, g, a.N, rk, ag, a.gen);
+  if (need) {
+    store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
+    if (sw.l == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
+  }
 }
 
 }  // namespace

@@ -2,6 +2,7 @@
 // plain and recording.
 #pragma once
 #include "rbg_kernels_stash.h"
+#include "rbg_regen.h"
 
 namespace {
 
@@ -33,6 +34,7 @@ struct RolloutArgs {
   int tick, ready_delay;
   TimestepPtrs traj;     // kRecord: every step's timestep, arrays [n_steps][B]... (members nullable)
   int32_t *traj_action;  // kRecord: the actions taken, [n_steps][B][N] (nullable)
+  GenSpec gen;           // the env's generator (rbg_regen.h); all zero = ParallelRandomWalk
 };
 
 // One env per sub-wave of LPB lanes (the host picks the smallest LPB that holds the walk's 2N + 2
@@ -66,9 +68,8 @@ __device__ __forceinline__ Key2 uni(Key2 k) {
 // per env at 16x16/10, which makes it an HBM stream instead of an LDS-resident loop.
 // (a recording full-wave env needs a few registers more than the 128 of four waves per SIMD
 // leave; it is HBM-bound, so three waves per SIMD cost it nothing)
-template <int LPB, bool kRecord>
-__global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLLOUT64_WAVES) : 2)) void connector_rollout_kernel(
-    RolloutArgs a) {
+template <int LPB, bool kRecord, int KIND>
+__device__ __forceinline__ void rollout_body(const RolloutArgs &a) {
   constexpr int kSubs = SubWave<LPB>::kSubs;
   const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
   const int l = sw.l;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLL
   const int b = (blockIdx.x * kWavesPerBlock + wib) * kSubs + sw.h;
   if (b >= a.B) return;  // per sub-wave: the rest of the wave carries on
   const Geo g = a.g;
-  uint32_t *board = g_lds + (wib * kSubs + sw.h) * slab_words<LPB>(g);
+  uint32_t *board = g_lds + (wib * kSubs + sw.h) * env_slab_words<LPB>(g, a.gen);
   uint32_t *W = board + board_words(g);
   const int N = a.N;
   const bool is_agent = l < N;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLL
         } else {
           Key2 rk, unused;
           split2_lanes(sw, key, rk, unused);
-          key = regenerate(sw, board, W, g, N, rk, ag);
+          key = regenerate_kind<LPB, KIND>(sw, board, W, g, N, rk, ag, a.gen);
         }
         step_count = 0;
         key = uni<LPB>(key);
@@ -159,6 +160,19 @@ __global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLL
     if (a.stats.final_connections) a.stats.final_connections[b] = fin_conn;
     if (a.stats.final_path_length) a.stats.final_path_length[b] = fin_plen;
   }
+}
+
+template <int LPB, bool kRecord>
+__global__ __launch_bounds__(kBlock, (LPB == kWaveSize ? (kRecord ? 3 : RBG_ROLLOUT64_WAVES) : 2)) void connector_rollout_kernel(
+    RolloutArgs a) {
+  rollout_body<LPB, kRecord, kGenPrw>(a);
+}
+
+// The rollout for the other generators of setup_train.py:112-152: one env per wavefront (the
+// SequentialRandomWalk needs the whole wave; the others keep one code shape), two waves per SIMD.
+template <int KIND, bool kRecord>
+__global__ __launch_bounds__(kBlock, 2) void connector_rollout_gen_kernel(RolloutArgs a) {
+  rollout_body<kWaveSize, kRecord, KIND>(a);
 }
 
 // The recording rollout's launch.

@@ -72,6 +72,11 @@ class BoardDatasetGeneratorJAX(Generator):
         st, _ = ops.dataset_sample(keys, self._heads, self._targets, self.grid_size)
         return state_from_bufs(st, batched)
 
+    def native_spec(self):
+        from .. import _native as nat
+
+        return ops.GeneratorSpec(nat.GEN_DATASET, heads=self._heads, targets=self._targets)
+
     def print_board(self, which_board: int) -> torch.Tensor:
         """:143-155 -- the training grid of board `which_board`."""
         grid = torch.zeros((self.grid_size, self.grid_size), dtype=torch.int32,

@@ -27,6 +27,11 @@ class ParallelRandomWalkGenerator(Generator):
               "step_count": out["step_count"]}
         return state_from_bufs(st, batched)
 
+    def native_spec(self):
+        from .. import _native as nat
+
+        return ops.GeneratorSpec(nat.GEN_PARALLEL_RW)
+
 
 class ParallelRandomWalkPhiloxGenerator(Generator):
     """The same walk on a counter-based Philox-4x32-10 stream instead of jax's Threefry key

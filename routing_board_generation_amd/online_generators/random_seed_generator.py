@@ -26,5 +26,12 @@ class SeedExtensionGenerator(Generator):
               "step_count": out["step_count"]}
         return state_from_bufs(st, batched)
 
+    def native_spec(self):
+        from .. import _native as nat
+
+        # random_seed_generator.py:36-37: generate_starts_ends(key) with its defaults
+        return ops.GeneratorSpec(nat.GEN_SEED_EXTENSION, randomness=0.0, two_sided=True,
+                                 extension_iterations=1, max_extension_steps=ops.INT32_MAX)
+
 
 RandomSeedGenerator = SeedExtensionGenerator

@@ -23,3 +23,10 @@ class SequentialRandomWalkGenerator(Generator):
               "position": out["position"], "key": out["key_out"],
               "step_count": out["step_count"]}
         return state_from_bufs(st, batched)
+
+    def native_spec(self):
+        from .. import _native as nat
+
+        # one refill launch lasts as long as its slowest board (~0.3 ms at 16x16/10): off the
+        # stepping stream, two slots per env
+        return ops.GeneratorSpec(nat.GEN_SEQUENTIAL_RW)

@@ -44,6 +44,12 @@ class Generator(abc.ABC):
     def __call__(self, key: torch.Tensor) -> State:
         """key (2,) -> State; key (B, 2) -> batched State (replaces jax.vmap(generator))."""
 
+    def native_spec(self):
+        """ops.GeneratorSpec of a generator that the env launches can run themselves (fused
+        reset, next-episode stash, fused rollouts: include/rbg_prw.h::rbg_generator), or None: a
+        user-defined generator is called from Python and `Connector` selects per env afterwards."""
+        return None
+
 
 class UniformRandomGenerator(Generator):
     """Start and target cells drawn uniformly without replacement (may be unsolvable)."""
@@ -53,3 +59,8 @@ class UniformRandomGenerator(Generator):
         keys = key if batched else key[None]
         st = ops.uniform_generate(keys.contiguous(), self.grid_size, self.num_agents)
         return state_from_bufs(st, batched)
+
+    def native_spec(self):
+        from .. import _native as nat
+
+        return ops.GeneratorSpec(nat.GEN_UNIFORM)

@@ -44,6 +44,43 @@ def _check(t: torch.Tensor, dtype: torch.dtype, shape, name: str) -> torch.Tenso
     return t
 
 
+INT32_MAX = 2 ** 31 - 1
+
+
+class GeneratorSpec:
+    """Host side of include/rbg_prw.h::rbg_generator: which generator (re)starts episodes inside
+    the env launches (setup_train.py:112-152), with the tensors it points to kept alive.
+    `refill` = how its next-episode stash is best refilled (EpochStash arguments; measured,
+    DESIGN.md 4.2)."""
+
+    def __init__(self, kind: int, randomness: float = 0.0, two_sided: bool = True,
+                 extension_iterations: int = 1, max_extension_steps: int = INT32_MAX,
+                 heads: Optional[torch.Tensor] = None, targets: Optional[torch.Tensor] = None,
+                 refill: Optional[dict] = None) -> None:
+        self.kind = int(kind)
+        n_boards = 0
+        if self.kind == nat.GEN_DATASET:
+            n_boards, N, _ = heads.shape
+            _check(heads, torch.int32, (n_boards, N, 2), "heads")
+            _check(targets, torch.int32, (n_boards, N, 2), "targets")
+        self._keepalive = (heads, targets)
+        self.struct = nat.Generator(self.kind, float(randomness), int(bool(two_sided)),
+                                    int(extension_iterations), int(max_extension_steps),
+                                    int(n_boards), _ptr(heads), _ptr(targets))
+        self.refill = dict(refill or {})
+
+    @property
+    def device(self):
+        return self._keepalive[0].device if self._keepalive[0] is not None else None
+
+
+def _gen_ref(gen: Optional["GeneratorSpec"]):
+    """Pointer argument for the *_gen entry points (None = ParallelRandomWalk)."""
+    if gen is None or gen.kind == nat.GEN_PARALLEL_RW:
+        return None
+    return C.byref(gen.struct)
+
+
 def check_keys(keys: torch.Tensor) -> torch.Tensor:
     if keys.dim() != 2 or keys.shape[1] != 2:
         raise ValueError(f"keys must have shape [B, 2], got {tuple(keys.shape)}")
@@ -245,9 +282,6 @@ def prw_generate_launcher(keys: torch.Tensor, m: int, N: int, split_first: bool,
     return launch
 
 
-INT32_MAX = 2 ** 31 - 1
-
-
 def extension_steps_to_int(extension_steps) -> int:
     """The reference compares an int32 sweep counter with `extension_steps` in float32
     (post_processor_utils_jax.py:51-55; default 1e23 = no limit): the number of sweeps allowed is
@@ -420,14 +454,17 @@ def prw_step_agent(grid: torch.Tensor, target: Optional[torch.Tensor], position:
 
 # ------------------------------------------------------------------------------------- Connector
 def connector_reset(keys: torch.Tensor, m: int, N: int, state: Optional[StateBufs] = None,
-                    timestep: Optional[TimestepBufs] = None):
+                    timestep: Optional[TimestepBufs] = None,
+                    gen: Optional[GeneratorSpec] = None):
+    """Connector(generator).reset(keys) in one launch; gen=None is the ParallelRandomWalk."""
     keys = check_keys(keys)
     B, dev = keys.shape[0], keys.device
     st = state if state is not None else alloc_state(B, m, N, dev)
     ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
     s, t = _state_struct(st, B, m, N), _timestep_struct(ts, B, m, N)
-    nat.check(nat.lib().rbg_connector_reset(keys.data_ptr(), B, m, N, C.byref(s), C.byref(t),
-                                            _stream(dev)), "rbg_connector_reset")
+    nat.check(nat.lib().rbg_connector_reset_gen(_gen_ref(gen), keys.data_ptr(), B, m, N,
+                                                C.byref(s), C.byref(t), None, 0, 0, _stream(dev)),
+              "rbg_connector_reset")
     return st, ts
 
 
@@ -445,8 +482,10 @@ def connector_observe(state: StateBufs, timestep: Optional[TimestepBufs] = None)
 def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
                    timestep_reward: float = -0.03, connected_reward: float = 0.1,
                    auto_reset: bool = False, state_out: Optional[StateBufs] = None,
-                   timestep: Optional[TimestepBufs] = None):
-    """state_out=None allocates a fresh state (functional); pass state_out=state to step in place."""
+                   timestep: Optional[TimestepBufs] = None,
+                   gen: Optional[GeneratorSpec] = None):
+    """state_out=None allocates a fresh state (functional); pass state_out=state to step in place.
+    `gen` = the generator that restarts finished episodes when auto_reset is set."""
     B, m, _ = state["grid"].shape
     N = state["start"].shape[1]
     dev = state["grid"].device
@@ -457,8 +496,9 @@ def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
     t = _timestep_struct(ts, B, m, N)
     p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
                       int(bool(auto_reset)))
-    nat.check(nat.lib().rbg_connector_step(B, m, N, C.byref(si), C.byref(s_o), action.data_ptr(),
-                                           C.byref(p), C.byref(t), _stream(dev)),
+    nat.check(nat.lib().rbg_connector_step_gen(_gen_ref(gen), B, m, N, C.byref(si), C.byref(s_o),
+                                               action.data_ptr(), None, 0, C.byref(p),
+                                               C.byref(t), None, 0, 0, _stream(dev)),
               "rbg_connector_step")
     return so, ts
 
@@ -492,14 +532,15 @@ def _stash_struct(stash: dict, B: int, m: int, N: int) -> nat.Stash:
 
 def connector_reset_prefetch(keys: torch.Tensor, m: int, N: int, stash: dict, tick: int,
                              ready_delay: int, state: Optional[StateBufs] = None,
-                             timestep: Optional[TimestepBufs] = None):
+                             timestep: Optional[TimestepBufs] = None,
+                             gen: Optional[GeneratorSpec] = None):
     keys = check_keys(keys)
     B, dev = keys.shape[0], keys.device
     st = state if state is not None else alloc_state(B, m, N, dev)
     ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
     s, t, h = _state_struct(st, B, m, N), _timestep_struct(ts, B, m, N), _stash_struct(stash, B, m, N)
-    nat.check(nat.lib().rbg_connector_reset_prefetch(
-        keys.data_ptr(), B, m, N, C.byref(s), C.byref(t), C.byref(h), int(tick),
+    nat.check(nat.lib().rbg_connector_reset_gen(
+        _gen_ref(gen), keys.data_ptr(), B, m, N, C.byref(s), C.byref(t), C.byref(h), int(tick),
         int(ready_delay), _stream(dev)), "rbg_connector_reset_prefetch")
     return st, ts
 
@@ -508,7 +549,8 @@ def connector_step_prefetch(state: StateBufs, action: torch.Tensor, stash: dict,
                             ready_delay: int, time_limit: int = 50,
                             timestep_reward: float = -0.03, connected_reward: float = 0.1,
                             state_out: Optional[StateBufs] = None,
-                            timestep: Optional[TimestepBufs] = None):
+                            timestep: Optional[TimestepBufs] = None,
+                            gen: Optional[GeneratorSpec] = None):
     """Auto-resetting step that takes finished episodes' next State from `stash` when it can."""
     B, m, _ = state["grid"].shape
     N = state["start"].shape[1]
@@ -519,18 +561,20 @@ def connector_step_prefetch(state: StateBufs, action: torch.Tensor, stash: dict,
     si, s_o = _state_struct(state, B, m, N), _state_struct(so, B, m, N)
     t, h = _timestep_struct(ts, B, m, N), _stash_struct(stash, B, m, N)
     p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward), 1)
-    nat.check(nat.lib().rbg_connector_step_prefetch(
-        B, m, N, C.byref(si), C.byref(s_o), action.data_ptr(), C.byref(p), C.byref(t),
-        C.byref(h), int(tick), int(ready_delay), _stream(dev)), "rbg_connector_step_prefetch")
+    nat.check(nat.lib().rbg_connector_step_gen(
+        _gen_ref(gen), B, m, N, C.byref(si), C.byref(s_o), action.data_ptr(), None, 0, C.byref(p),
+        C.byref(t), C.byref(h), int(tick), int(ready_delay), _stream(dev)),
+        "rbg_connector_step_prefetch")
     return so, ts
 
 
-def stash_refill(stash: dict, m: int) -> None:
+def stash_refill(stash: dict, m: int, gen: Optional[GeneratorSpec] = None) -> None:
     """Launch the refill on torch's current stream."""
     B, N = stash["hits"].shape[0], stash["next"]["start"].shape[1]
     dev = stash["tag"].device
     h = _stash_struct(stash, B, m, N)
-    nat.check(nat.lib().rbg_stash_refill(B, m, N, C.byref(h), _stream(dev)), "rbg_stash_refill")
+    nat.check(nat.lib().rbg_stash_refill_gen(_gen_ref(gen), B, m, N, C.byref(h), _stream(dev)),
+              "rbg_stash_refill")
 
 
 class EpochStash:
@@ -547,10 +591,12 @@ class EpochStash:
     of epoch e + 2 (one stream event per epoch); entries are usable from tick K * (e + 2) on."""
 
     def __init__(self, B: int, m: int, N: int, device, every: int, serial: bool = True,
-                 depth: int = 1) -> None:
+                 depth: int = 1, gen: Optional[GeneratorSpec] = None) -> None:
         """depth=2: two slots per env, every entry requested a whole episode before it is needed
-        (include/rbg_prw.h::rbg_stash) -- for launches of many steps (connector_rollout)."""
+        (include/rbg_prw.h::rbg_stash) -- for launches of many steps (connector_rollout).
+        gen: the generator whose producer refills the stash (None = ParallelRandomWalk)."""
         self.B, self.m, self.N, self.device = B, m, N, device
+        self.gen, self._g = gen, _gen_ref(gen)
         self.K = max(1, int(every))
         self.serial = bool(serial)
         self.tick = 0
@@ -582,17 +628,18 @@ class EpochStash:
         if self.tick % K == K - 1:
             if self.serial:
                 sp = C.c_void_p(stream.cuda_stream) if stream is not None else _stream(self.device)
-                nat.check(self._lib.rbg_stash_refill(self.B, self.m, self.N, C.byref(self.struct),
-                                                     sp), "rbg_stash_refill")
+                nat.check(self._lib.rbg_stash_refill_gen(self._g, self.B, self.m, self.N,
+                                                         C.byref(self.struct), sp),
+                          "rbg_stash_refill")
             else:
                 stream = stream or torch.cuda.current_stream(self.device)
                 side = self._sides[e % 2]
                 ev = self._launched[e % 4]
                 ev.record(stream)
                 side.wait_event(ev)
-                nat.check(self._lib.rbg_stash_refill(self.B, self.m, self.N,
-                                                     C.byref(self.struct),
-                                                     C.c_void_p(side.cuda_stream)),
+                nat.check(self._lib.rbg_stash_refill_gen(self._g, self.B, self.m, self.N,
+                                                         C.byref(self.struct),
+                                                         C.c_void_p(side.cuda_stream)),
                           "rbg_stash_refill")
                 self._done[e % 4].record(side)
         self.tick += 1
@@ -621,7 +668,8 @@ class StepLoop:
                  time_limit: int = 50, timestep_reward: float = -0.03,
                  connected_reward: float = 0.1, refill_every: int = 0,
                  fuse_policy: bool = False, auto_reset: bool = True,
-                 serial_refill: bool = True, stash_depth: int = 1) -> None:
+                 serial_refill: bool = True, stash_depth: int = 1,
+                 gen: Optional[GeneratorSpec] = None) -> None:
         B, m, _ = state["grid"].shape
         N = state["start"].shape[1]
         dev = state["grid"].device
@@ -638,10 +686,13 @@ class StepLoop:
         self._main = C.c_void_p(self._main_stream.cuda_stream)
         self.K = max(0, int(refill_every))
         self.fuse_policy = bool(fuse_policy)  # policy + step in ONE launch (rollout of 1 step)
-        self._epochs = (EpochStash(B, m, N, dev, self.K, serial=serial_refill, depth=stash_depth)
-                        if self.K else None)
+        self.gen, self._g = gen, _gen_ref(gen)
+        self._epochs = (EpochStash(B, m, N, dev, self.K, serial=serial_refill, depth=stash_depth,
+                                   gen=gen) if self.K else None)
+        self._hp = None
         if self.K:
             self.stash, self._h = self._epochs.stash, self._epochs.struct
+            self._hp = C.byref(self._h)
 
     @property
     def tick(self) -> int:
@@ -662,57 +713,39 @@ class StepLoop:
         keys = check_keys(keys)
         if self.K:
             self._before_launch()
-            nat.check(self._lib.rbg_connector_reset_prefetch(
-                keys.data_ptr(), self.B, self.m, self.N, C.byref(self._s), C.byref(self._t),
-                C.byref(self._h), self.tick, self._ready_delay(), self._main),
-                "rbg_connector_reset_prefetch")
+        nat.check(self._lib.rbg_connector_reset_gen(
+            self._g, keys.data_ptr(), self.B, self.m, self.N, C.byref(self._s), C.byref(self._t),
+            self._hp, self.tick, self._ready_delay() if self.K else 0, self._main),
+            "rbg_connector_reset")
+        if self.K:
             self._after_launch()
-        else:
-            nat.check(self._lib.rbg_connector_reset(
-                keys.data_ptr(), self.B, self.m, self.N, C.byref(self._s), C.byref(self._t),
-                self._main), "rbg_connector_reset")
 
     def step(self, t: int, action: Optional[torch.Tensor] = None) -> None:
         """Policy at global step t, then one auto-resetting env step, in place.  With `action`
         (int32 [B, N], e.g. recorded from an earlier pass) the policy launch is skipped."""
         lib = self._lib
-        if self.fuse_policy and action is None:
-            if self.K:
-                self._before_launch()
-            rc = lib.rbg_connector_rollout_prefetch(
-                self.B, self.m, self.N, C.byref(self._s), C.byref(self._s), self.keys.data_ptr(),
-                int(t) & 0xFFFFFFFF, 1, C.byref(self._p), None, C.byref(self._t),
-                C.byref(self._h) if self.K else None, self.tick,
-                self._ready_delay() if self.K else 0, self._main)
-            if rc:
-                nat.check(rc, "rbg_connector_rollout_prefetch")
-            if self.K:
-                self._after_launch()
-            return
-        if action is None:
+        pol_ptr, act_ptr = None, None
+        if action is not None:
+            act_ptr = _check(action, torch.int32, (self.B, self.N), "action").data_ptr()
+        elif self.fuse_policy:  # policy + step in ONE launch
+            pol_ptr = self.keys.data_ptr()
+        else:
             rc = lib.rbg_random_actions(self.keys.data_ptr(), self.B, self.N, int(t) & 0xFFFFFFFF,
                                         self.timestep["action_mask"].data_ptr(),
                                         self.action.data_ptr(), self._main)
             if rc:
                 nat.check(rc, "rbg_random_actions")
             act_ptr = self.action.data_ptr()
-        else:
-            act_ptr = _check(action, torch.int32, (self.B, self.N), "action").data_ptr()
         if self.K:
             self._before_launch()
-            rc = lib.rbg_connector_step_prefetch(
-                self.B, self.m, self.N, C.byref(self._s), C.byref(self._s), act_ptr,
-                C.byref(self._p), C.byref(self._t), C.byref(self._h), self.tick,
-                self._ready_delay(), self._main)
-            if rc:
-                nat.check(rc, "rbg_connector_step_prefetch")
+        rc = lib.rbg_connector_step_gen(
+            self._g, self.B, self.m, self.N, C.byref(self._s), C.byref(self._s), act_ptr, pol_ptr,
+            int(t) & 0xFFFFFFFF, C.byref(self._p), C.byref(self._t), self._hp, self.tick,
+            self._ready_delay() if self.K else 0, self._main)
+        if rc:
+            nat.check(rc, "rbg_connector_step")
+        if self.K:
             self._after_launch()
-        else:
-            rc = lib.rbg_connector_step(self.B, self.m, self.N, C.byref(self._s), C.byref(self._s),
-                                        act_ptr, C.byref(self._p),
-                                        C.byref(self._t), self._main)
-            if rc:
-                nat.check(rc, "rbg_connector_step")
 
     def drain(self) -> None:
         """Make the main stream wait for every refill in flight (before freeing the buffers)."""
@@ -739,10 +772,17 @@ class ConnectorSession:
     def __init__(self, B: int, m: int, N: int, device, time_limit: int = 50,
                  timestep_reward: float = -0.03, connected_reward: float = 0.1,
                  auto_reset: bool = False, refill_every: int = 0, donate: bool = False,
-                 aggregate: bool = False) -> None:
+                 aggregate: bool = False, gen: Optional[GeneratorSpec] = None,
+                 chunk_steps: Optional[int] = None) -> None:
         """aggregate=True: the timestep carries reward_total / discount_max [B]
-        (MultiToSingleWrapper inside the launch) instead of per-agent reward / discount."""
+        (MultiToSingleWrapper inside the launch) instead of per-agent reward / discount.
+        gen: the env's generator (None = ParallelRandomWalk).
+        chunk_steps: steps per output chunk (default: as many as fit 1 GiB per field, at most 16).
+        Every step's output tensors are views into a chunk, so a TimeStep kept alive (a replay
+        buffer sampling every k-th step) pins the whole chunk -- up to chunk_steps times its own
+        size; .clone() what is retained, or pass chunk_steps=1."""
         self.B, self.m, self.N, self.device = B, m, N, device
+        self.gen, self._g = gen, _gen_ref(gen)
         self.donate, self.aggregate = bool(donate), bool(aggregate)
         self._ring, self._ring_i = None, 0
         self._lib = nat.lib()
@@ -770,7 +810,8 @@ class ConnectorSession:
             ("ratio_connections", f32, (B,)), ("total_path_length", i32, (B,)),
             ("reward_total", f32 if aggregate else None, (B,)),
             ("discount_max", f32 if aggregate else None, (B,)))  # dtype None: output not wanted
-        self.chunk_steps = max(1, min(16, (1 << 30) // (4 * B * N * m * m)))
+        self.chunk_steps = (max(1, int(chunk_steps)) if chunk_steps else
+                            max(1, min(16, (1 << 30) // (4 * B * N * m * m))))
         self._views, self._bases, self._cursor = None, None, 0
 
     def _fresh(self):
@@ -817,15 +858,19 @@ class ConnectorSession:
         if self.K:
             if self.epochs is not None:
                 self.epochs.drain()
-            ep = self.epochs = EpochStash(self.B, self.m, self.N, self.device, self.K)
+            kw = dict(self.gen.refill) if self.gen is not None else {}
+            kw.pop("every", None)
+            ep = self.epochs = EpochStash(self.B, self.m, self.N, self.device, self.K,
+                                          gen=self.gen, **kw)
             ep.before_launch()
-            rc = self._lib.rbg_connector_reset_prefetch(
-                keys.data_ptr(), self.B, self.m, self.N, C.byref(s), C.byref(t),
+            rc = self._lib.rbg_connector_reset_gen(
+                self._g, keys.data_ptr(), self.B, self.m, self.N, C.byref(s), C.byref(t),
                 C.byref(ep.struct), ep.tick, ep.ready_delay(), _stream(self.device))
             ep.after_launch()
         else:
-            rc = self._lib.rbg_connector_reset(keys.data_ptr(), self.B, self.m, self.N,
-                                               C.byref(s), C.byref(t), _stream(self.device))
+            rc = self._lib.rbg_connector_reset_gen(
+                self._g, keys.data_ptr(), self.B, self.m, self.N, C.byref(s), C.byref(t), None,
+                0, 0, _stream(self.device))
         if rc:
             nat.check(rc, "rbg_connector_reset")
         self._last = (st, s)
@@ -847,15 +892,15 @@ class ConnectorSession:
         ep = self.epochs
         if ep is not None:
             ep.before_launch()
-            rc = self._lib.rbg_connector_step_prefetch(
-                self.B, self.m, self.N, C.byref(si), C.byref(s), action.data_ptr(),
-                C.byref(self._p), C.byref(t), C.byref(ep.struct), ep.tick, ep.ready_delay(),
+            rc = self._lib.rbg_connector_step_gen(
+                self._g, self.B, self.m, self.N, C.byref(si), C.byref(s), action.data_ptr(), None,
+                0, C.byref(self._p), C.byref(t), C.byref(ep.struct), ep.tick, ep.ready_delay(),
                 _stream(self.device))
             ep.after_launch()
         else:
-            rc = self._lib.rbg_connector_step(
-                self.B, self.m, self.N, C.byref(si), C.byref(s), action.data_ptr(),
-                C.byref(self._p), C.byref(t), _stream(self.device))
+            rc = self._lib.rbg_connector_step_gen(
+                self._g, self.B, self.m, self.N, C.byref(si), C.byref(s), action.data_ptr(), None,
+                0, C.byref(self._p), C.byref(t), None, 0, 0, _stream(self.device))
         if rc:
             nat.check(rc, "rbg_connector_step")
         self._last = (st, s)
@@ -875,7 +920,8 @@ def connector_rollout(state: StateBufs, policy_keys: torch.Tensor, t0: int, n_st
                       connected_reward: float = 0.1, auto_reset: bool = True,
                       state_out: Optional[StateBufs] = None, stats: Optional[dict] = None,
                       timestep: Optional[TimestepBufs] = None, want_timestep: bool = False,
-                      epochs: Optional["EpochStash"] = None):
+                      epochs: Optional["EpochStash"] = None,
+                      gen: Optional[GeneratorSpec] = None):
     """n_steps of random-policy stepping in one launch.  Returns (state_out, stats, timestep);
     timestep is None unless a buffer dict is passed or want_timestep is set.  `epochs` (an
     EpochStash, best with depth=2 and every=1) serves the resets from the next-episode stash and
@@ -899,21 +945,20 @@ def connector_rollout(state: StateBufs, policy_keys: torch.Tensor, t0: int, n_st
     p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
                       int(bool(auto_reset)))
     tp = _timestep_struct(ts, B, m, N) if ts is not None else None
-    if epochs is not None and auto_reset:
+    use_stash = epochs is not None and auto_reset
+    if use_stash:
         if (epochs.B, epochs.m, epochs.N) != (B, m, N):
             raise ValueError("epochs was built for another batch / grid / agent count")
         epochs.before_launch()
-        rc = nat.lib().rbg_connector_rollout_prefetch(
-            B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(), int(t0) & 0xFFFFFFFF,
-            int(n_steps), C.byref(p), C.byref(sp), C.byref(tp) if tp is not None else None,
-            C.byref(epochs.struct), epochs.tick, epochs.ready_delay(), _stream(dev))
+    rc = nat.lib().rbg_connector_rollout_gen(
+        _gen_ref(gen), B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(),
+        int(t0) & 0xFFFFFFFF, int(n_steps), C.byref(p), C.byref(sp),
+        C.byref(tp) if tp is not None else None, None, None,
+        C.byref(epochs.struct) if use_stash else None, epochs.tick if use_stash else 0,
+        epochs.ready_delay() if use_stash else 0, _stream(dev))
+    if use_stash:
         epochs.after_launch()
-        nat.check(rc, "rbg_connector_rollout_prefetch")
-        return so, st, ts
-    nat.check(nat.lib().rbg_connector_rollout(
-        B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(), int(t0) & 0xFFFFFFFF,
-        int(n_steps), C.byref(p), C.byref(sp), C.byref(tp) if tp is not None else None,
-        _stream(dev)), "rbg_connector_rollout")
+    nat.check(rc, "rbg_connector_rollout")
     return so, st, ts
 
 
@@ -932,7 +977,8 @@ def connector_rollout_record(state: StateBufs, policy_keys: torch.Tensor, t0: in
                              state_out: Optional[StateBufs] = None,
                              trajectory: Optional[TimestepBufs] = None,
                              stats: Optional[dict] = None, with_obs_grid: bool = True,
-                             epochs: Optional["EpochStash"] = None):
+                             epochs: Optional["EpochStash"] = None,
+                             gen: Optional[GeneratorSpec] = None):
     """connector_rollout that also records every step's timestep and action: returns
     (state_out, stats, trajectory) with trajectory[field] of shape [n_steps, B, ...] -- row s is
     what the s-th `VmapAutoResetWrapper(env).step` of the loop returns."""
@@ -967,8 +1013,9 @@ def connector_rollout_record(state: StateBufs, policy_keys: torch.Tensor, t0: in
         if (epochs.B, epochs.m, epochs.N) != (B, m, N):
             raise ValueError("epochs was built for another batch / grid / agent count")
         epochs.before_launch()
-    rc = nat.lib().rbg_connector_rollout_record(
-        B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(), int(t0) & 0xFFFFFFFF, T,
+    rc = nat.lib().rbg_connector_rollout_gen(
+        _gen_ref(gen), B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(),
+        int(t0) & 0xFFFFFFFF, T,
         C.byref(p), C.byref(sp), None, C.byref(tp), _ptr(action),
         C.byref(epochs.struct) if use_stash else None, epochs.tick if use_stash else 0,
         epochs.ready_delay() if use_stash else 0, _stream(dev))

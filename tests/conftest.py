@@ -52,8 +52,7 @@ def slow_path_lib(tmp_path_factory):
     from routing_board_generation_amd import _native as nat
 
     so = str(tmp_path_factory.mktemp("variant") / "librbg_slow_paths.so")
-    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + nat.HIPCC_FLAGS +
-                          ["-DRBG_SE_MARGIN=0", "-DRBG_SEQ_HISTORY_BYTES=0", "-o", so, nat.SRC_PATH])
+    nat.hipcc_compile(["-DRBG_SE_MARGIN=0", "-DRBG_SEQ_HISTORY_BYTES=0", "-o", so, nat.SRC_PATH])
     lib = C.CDLL(so)
     for name, (restype, argtypes) in nat.SIGNATURES.items():
         getattr(lib, name).restype, getattr(lib, name).argtypes = restype, argtypes

@@ -1,0 +1,223 @@
+"""GPU parity of the coupled env path for EVERY generator the reference can put behind Connector
+(routing_board_generation/rl_training/setup_train.py:112-161: offline_seed_extension,
+offline_parallel_rw, online_uniform, online_seq_rw, online_random_seed, online_parallel_rw).
+
+The oracle side is composed from pieces that are each pinned or compared elsewhere:
+  connector_step_batch(auto_reset=False)  +  generator batch call on split(state.key)[0] for the
+  envs whose timestep is LAST  +  connector_observe_batch of the fresh states
+which is [3P] jumanji.wrappers.VmapAutoResetWrapper._auto_reset written out (only the observation
+of the terminal timestep is replaced).  State and the full timestep are compared after every step.
+
+Parity status: the env semantics are "parity unpinned" (DESIGN.md section 2): these tests compare
+the HIP path with this project's oracle.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_dicts_equal, state_to_np, timestep_to_np, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rbg():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (there is no CPU fallback to hide behind)")
+    import routing_board_generation_amd as pkg
+
+    pkg._native.lib()
+    return pkg
+
+
+def _keys(rbg, seed, B):
+    return rbg.split(rbg.PRNGKey(seed), B)
+
+
+GENERATORS = ["online_parallel_rw", "online_uniform", "online_seq_rw", "online_random_seed",
+              "offline_parallel_rw", "offline_seed_extension"]
+
+
+def make_pair(rbg, oracle, name, m, N, n_boards=64):
+    """(package generator, oracle batch function keys [B, 2] -> state dict)."""
+    from routing_board_generation_amd.interface.board_generator_interface import make_online_generator
+
+    if name.startswith("offline"):
+        # cfg.env.seed_extension.* of agent_training/configs/env/connector.yaml go to the dataset
+        gen = make_online_generator(name, m, N, randomness=0.0, two_sided=True,
+                                    extension_iterations=1, extension_steps=1e23,
+                                    number_of_boards=n_boards)
+        heads, targets = to_np(gen._heads), to_np(gen._targets)
+        return gen, lambda keys: oracle.dataset_sample_batch(keys, heads, targets, m)[0]
+    gen = make_online_generator(name, m, N)
+    if name == "online_parallel_rw":
+        return gen, lambda keys: oracle.generate_batch(keys, m, N, "parallel_random_walk",
+                                                       threads=8, want_solved=False)[0]
+    if name == "online_uniform":
+        return gen, lambda keys: oracle.generate_batch(keys, m, N, "uniform", threads=8,
+                                                       want_solved=False)[0]
+    if name == "online_seq_rw":
+        return gen, lambda keys: oracle.seq_rw_generator_batch(keys, m, N, threads=8)[0]
+    if name == "online_random_seed":
+        return gen, lambda keys: oracle.seed_extension_batch(keys, m, N, split_first=True,
+                                                             threads=8)[0]
+    raise ValueError(name)
+
+
+def oracle_reset(oracle, gen_fn, keys):
+    st = gen_fn(keys)
+    return st, oracle.connector_observe_batch(st, threads=8)
+
+
+def oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl):
+    """VmapAutoResetWrapper(Connector(g)).step on the oracle side; steps `est` in place."""
+    ets = oracle.connector_step_batch(est, eaction, time_limit=tl, auto_reset=False, threads=8)
+    idx = np.nonzero(ets["step_type"] == 2)[0]
+    if idx.size:
+        new_keys = np.stack([oracle.split(k)[0] for k in est["key"][idx]])
+        fresh = gen_fn(new_keys)
+        fts = oracle.connector_observe_batch(fresh, threads=8)
+        for f in est:
+            est[f][idx] = fresh[f]
+        for f in ("obs_grid", "action_mask", "obs_step_count"):
+            ets[f][idx] = fts[f]
+    return ets
+
+
+def aggregate(ets, N):
+    """MultiToSingleWrapper: reward ((0 + r_0) + r_1) + ... in float32, discount max."""
+    out = dict(ets)
+    total = np.zeros(ets["reward"].shape[:1], dtype=np.float32)
+    for i in range(N):
+        total = (total + ets["reward"][:, i]).astype(np.float32)
+    out["reward"] = total
+    out["discount"] = ets["discount"].max(axis=1)
+    return out
+
+
+@pytest.mark.parametrize("prefetch,delay", [(False, 0), (True, 1), (True, 5)])
+@pytest.mark.parametrize("name", GENERATORS)
+def test_auto_reset_rollout_matches_oracle(rbg, oracle, name, prefetch, delay):
+    """The reference's training env VmapAutoResetWrapper(MultiToSingleWrapper(Connector(g)))
+    (setup_train.py:158-167) for every generation_type, several episodes at 16x16/10 under random
+    legal actions: state and full timestep after every step."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, steps, tl = 16, 10, 96, 40, 9
+    gen, gen_fn = make_pair(rbg, oracle, name, m, N)
+    env = rbg.VmapAutoResetWrapper(rbg.MultiToSingleWrapper(
+        rbg.Connector(generator=gen, time_limit=tl)), prefetch=prefetch, prefetch_delay=delay)
+    keys, akeys = _keys(rbg, 31, B), _keys(rbg, 32, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
+    assert_dicts_equal(state_to_np(state), est, "reset state.")
+    for f in ("obs_grid", "action_mask", "obs_step_count", "num_connections", "total_path_length"):
+        assert (timestep_to_np(ts)[f] == ets[f]).all(), f
+    assert ts.reward.shape == (B,) and (to_np(ts.reward) == 0).all()
+    n_last = 0
+    for t in range(steps):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        assert (to_np(action) == eaction).all(), f"policy diverged at step {t}"
+        state, ts = env.step(state, action)
+        ets = oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl)
+        assert_dicts_equal(state_to_np(state), est, f"{name} step {t} state.")
+        assert_dicts_equal(timestep_to_np(ts), aggregate(ets, N), f"{name} step {t} timestep.")
+        n_last += int(to_np(ts.last()).sum())
+    assert n_last >= 3 * B, "several episodes per env were expected"
+    for sess in env.unwrapped._sessions.values():
+        if prefetch:
+            # the generator's own refill producer served the restarts (an entry is usable at most
+            # 2 * delay launches after its request; episodes last up to 9 steps)
+            hits = int(to_np(sess.epochs.stash["hits"]).sum())
+            assert hits >= (0.8 if delay == 1 else 0.3) * n_last, (hits, n_last)
+        sess.drain()
+
+
+@pytest.mark.parametrize("name", GENERATORS)
+def test_native_generators_take_the_fused_path(rbg, name):
+    """Every generator of setup_train.py:112-152 steps through ONE launch per step: the Connector
+    must not fall back to regenerate-every-env-every-step (Connector._generic_auto_reset)."""
+    import torch
+
+    from routing_board_generation_amd.interface.board_generator_interface import make_online_generator
+
+    kw = dict(randomness=0.0, two_sided=True, number_of_boards=16) if name.startswith("offline") else {}
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=make_online_generator(name, 8, 3, **kw),
+                                                 time_limit=2))
+
+    def refuse(*a, **k):
+        raise AssertionError("generic auto-reset path taken")
+
+    env.unwrapped._generic_auto_reset = refuse
+    state, ts = env.reset(_keys(rbg, 3, 16))
+    for _ in range(5):
+        state, ts = env.step(state, torch.zeros((16, 3), dtype=torch.int32, device="cuda"))
+    assert int(to_np(state.step_count).max()) <= 2
+
+
+class _PythonGenerator:
+    """A user-defined generator (no native producer): the documented fallback path."""
+
+    def __init__(self, inner):
+        self._inner = inner
+        self.grid_size, self.num_agents = inner.grid_size, inner.num_agents
+
+    def __call__(self, key):
+        return self._inner(key)
+
+
+def test_user_defined_generator_still_works_through_the_generic_path(rbg, oracle):
+    from routing_board_generation_amd import ops
+
+    m, N, B, tl = 8, 4, 32, 4
+    gen = _PythonGenerator(rbg.UniformRandomGenerator(m, N))
+    gen_fn = lambda keys: oracle.generate_batch(keys, m, N, "uniform", want_solved=False)[0]
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl))
+    keys, akeys = _keys(rbg, 6, B), _keys(rbg, 7, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
+    for t in range(11):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        state, ts = env.step(state, action)
+        ets = oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl)
+        assert_dicts_equal(state_to_np(state), est, f"step {t} state.")
+        assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
+
+
+@pytest.mark.parametrize("record", [False, True])
+@pytest.mark.parametrize("prefetch", [False, True])
+@pytest.mark.parametrize("name", GENERATORS)
+def test_fused_random_rollout_for_every_generator(rbg, oracle, name, prefetch, record):
+    """benchmark_on_random_agent.py:59-102 runs on whatever generator the config names: the fused
+    (and the recording) rollout launch against the oracle's step-by-step loop."""
+    m, N, B, tl, n_steps = 16, 10, 64, 7, 12
+    gen, gen_fn = make_pair(rbg, oracle, name, m, N)
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl),
+                                   prefetch=prefetch, prefetch_delay=1)
+    keys, akeys = _keys(rbg, 41, B), _keys(rbg, 42, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
+    t0 = 0
+    for launch in range(3):
+        if record:
+            state, actions, traj = env.random_rollout(state, akeys, t0, n_steps, record=True)
+            tnp = {k: v for k, v in timestep_to_np(traj).items()}
+        else:
+            state, stats, last = env.random_rollout(state, akeys, t0, n_steps, want_timestep=True)
+        episodes = np.zeros((B,), np.int32)
+        for s in range(n_steps):
+            eaction = oracle.random_actions_batch(to_np(akeys), t0 + s, ets["action_mask"])
+            ets = oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl)
+            episodes += (ets["step_type"] == 2).astype(np.int32)
+            if record:
+                assert (to_np(actions[s]) == eaction).all(), (launch, s)
+                assert_dicts_equal({k: v[s] for k, v in tnp.items()}, ets,
+                                   f"{name} launch {launch} step {s} trajectory.")
+        assert_dicts_equal(state_to_np(state), est, f"{name} launch {launch} state.")
+        if not record:
+            assert (to_np(stats["episodes"]) == episodes).all()
+            assert_dicts_equal(timestep_to_np(last), ets, f"{name} launch {launch} last timestep.")
+        t0 += n_steps
