@@ -226,6 +226,8 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  *   ready_at    int32 [depth*B]: first launch tick that may consume the row (zero-initialised)
  *   refill_key  uint32 [depth*B][2]: the State.key whose successor the row should hold next
  *   hits        int32 [B], nullable: resets served from the stash (diagnostics; caller zeroes)
+ *   misses      int32 [B], nullable: resets of a stash-backed launch that had to run the generator
+ *               inline (caller zeroes; a host that sees them grow refills more often)
  * Protocol (host-driven, kernel boundaries only -- no in-kernel cross-stream flags):
  *   every reset/step launch has a tick t = 0, 1, 2, ...  A launch that (re)starts env b with
  *   State.key k writes requests (refill_key, ready_at = t + ready_delay), where the caller
@@ -248,6 +250,7 @@ typedef struct rbg_stash {
   int32_t *ready_at;
   uint32_t *refill_key;
   int32_t *hits;
+  int32_t *misses;
   int32_t depth;
 } rbg_stash;
 

@@ -91,7 +91,8 @@ class Connector:
         self.grid_size = self._generator.grid_size
         self._viewer = viewer
         self._auto_reset = False  # switched on by VmapAutoResetWrapper
-        self._prefetch_delay = 0  # > 0: VmapAutoResetWrapper(prefetch=True)
+        self._prefetch_delay = 0  # VmapAutoResetWrapper(prefetch=True): > 0, or None = the
+        #                           generator's own schedule (ops.GeneratorSpec.refill)
         self._donate = bool(donate)
         self._aggregate = False  # switched on by MultiToSingleWrapper
         self._sessions = {}  # (B, device, wrapper + env parameters) -> ops.ConnectorSession
@@ -113,7 +114,10 @@ class Connector:
         """The launch context of batched reset/step calls (ops.ConnectorSession), one per batch
         size / device / wrapper configuration."""
         fused_reset = self._auto_reset and self._gen is not None
-        k = (B, device, fused_reset, self._prefetch_delay, self._donate, self._aggregate,
+        delay = self._prefetch_delay
+        if delay is None:
+            delay = self._gen.refill.get("every", 16) if self._gen is not None else 0
+        k = (B, device, fused_reset, delay, self._donate, self._aggregate,
              self.time_limit,
              self._reward_fn.timestep_reward, self._reward_fn.connected_reward)
         sess = self._sessions.get(k)
@@ -123,7 +127,7 @@ class Connector:
             sess = self._sessions[k] = ops.ConnectorSession(
                 B, self.grid_size, self.num_agents, device, self.time_limit,
                 self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
-                auto_reset=fused_reset, refill_every=self._prefetch_delay, donate=self._donate,
+                auto_reset=fused_reset, refill_every=delay, donate=self._donate,
                 aggregate=self._aggregate, gen=self._gen)
         return sess
 
@@ -212,7 +216,7 @@ class Connector:
                 "fused rollouts need a generator the launch can run itself (Generator.native_spec); "
                 "a user-defined Python generator steps through Connector.step")
         epochs = None
-        if self._auto_reset and self._prefetch_delay > 0:
+        if self._auto_reset and self._prefetch_delay != 0:
             # two-slot next-episode stash, refilled after every launch: also an env that finishes
             # two episodes within the launch finds both successors ready
             B, dev = state.grid.shape[0], state.grid.device

@@ -44,15 +44,20 @@ class VmapAutoResetWrapper(_Wrapper):
     the same kernel launch from split(state.key)[0], keeping reward/discount/step_type/extras of
     the terminal step and replacing only the observation."""
 
-    def __init__(self, env, prefetch: bool = True, prefetch_delay: int = 16, donate=None):
+    def __init__(self, env, prefetch: bool = True, prefetch_delay=None, donate=None):
         """prefetch=True (default) generates every env's NEXT episode ahead of time
-        (include/rbg_prw.h::rbg_stash): one refill launch per `prefetch_delay` steps walks for all
-        the envs that restarted since the last one, instead of every step launch waiting for the
-        walks of its own finished envs; results are identical with and without it.
+        (include/rbg_prw.h::rbg_stash): one refill launch per `prefetch_delay` steps runs the
+        generator for all the envs that restarted since the last one, instead of every step launch
+        waiting for the generator runs of its own finished envs; results are identical with and
+        without it.  prefetch_delay=None takes the generator's measured best
+        (ops.GeneratorSpec.refill: 16 steps for ParallelRandomWalk, 48 with two slots per env for
+        SequentialRandomWalk / SeedExtension, none for Uniform and the offline dataset, whose
+        "generation" is cheaper than a stash row copy).
         donate=True/False overrides the env's setting (Connector(donate=...))."""
         super().__init__(env)
         env.unwrapped._auto_reset = True
-        env.unwrapped._prefetch_delay = int(prefetch_delay) if prefetch else 0
+        env.unwrapped._prefetch_delay = (0 if not prefetch else
+                                         None if prefetch_delay is None else int(prefetch_delay))
         if donate is not None:
             env.unwrapped._donate = bool(donate)
 

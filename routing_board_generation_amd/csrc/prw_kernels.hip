@@ -414,6 +414,7 @@ static int fill_stash(const rbg_stash *stash, StashPtrs *out, const char *who) {
   out->ready_at = stash->ready_at;
   out->refill_key = stash->refill_key;
   out->hits = stash->hits;
+  out->misses = stash->misses;
   out->depth = stash->depth;
   if (stash->depth != 1 && stash->depth != 2) {
     snprintf(g_err, sizeof(g_err), "%s: stash depth must be 1 or 2", who);

@@ -134,6 +134,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a) {
           load_state(sw, board, g, N, row, a.stash.next, ag, step_count, key);
           if (a.stash.hits && l == 0) a.stash.hits[b] += 1;
         } else {
+          if (a.stash.misses && l == 0) a.stash.misses[b] += 1;
           Key2 rk, unused;
           split2_lanes(sw, key, rk, unused);
           key = regenerate_kind<LPB, KIND>(sw, board, W, g, N, rk, ag, a.gen);

@@ -13,6 +13,7 @@ struct StashPtrs {
   int32_t *ready_at;     // [depth*B] first launch tick that may consume the row
   uint32_t *refill_key;  // [depth*B][2] the State.key whose successor the row should hold next
   int32_t *hits;         // [B] nullable diagnostics: resets served from the stash
+  int32_t *misses;       // [B] nullable: resets that ran the generator inline although a stash exists
   int depth;             // 1 or 2
 };
 

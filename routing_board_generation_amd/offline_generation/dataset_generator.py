@@ -75,7 +75,9 @@ class BoardDatasetGeneratorJAX(Generator):
     def native_spec(self):
         from .. import _native as nat
 
-        return ops.GeneratorSpec(nat.GEN_DATASET, heads=self._heads, targets=self._targets)
+        # sampling a stored board is cheaper than a stash row copy: no stash
+        return ops.GeneratorSpec(nat.GEN_DATASET, heads=self._heads, targets=self._targets,
+                                 refill={"every": 0})
 
     def print_board(self, which_board: int) -> torch.Tensor:
         """:143-155 -- the training grid of board `which_board`."""

@@ -30,8 +30,10 @@ class SeedExtensionGenerator(Generator):
         from .. import _native as nat
 
         # random_seed_generator.py:36-37: generate_starts_ends(key) with its defaults
+        # (refill: as for SequentialRandomWalk -- a launch of ~1.4 ms whatever its row count)
         return ops.GeneratorSpec(nat.GEN_SEED_EXTENSION, randomness=0.0, two_sided=True,
-                                 extension_iterations=1, max_extension_steps=ops.INT32_MAX)
+                                 extension_iterations=1, max_extension_steps=ops.INT32_MAX,
+                                 refill={"every": 48, "depth": 2, "adaptive": True})
 
 
 RandomSeedGenerator = SeedExtensionGenerator

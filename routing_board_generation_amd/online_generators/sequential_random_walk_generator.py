@@ -27,6 +27,6 @@ class SequentialRandomWalkGenerator(Generator):
     def native_spec(self):
         from .. import _native as nat
 
-        # one refill launch lasts as long as its slowest board (~0.3 ms at 16x16/10): off the
-        # stepping stream, two slots per env
-        return ops.GeneratorSpec(nat.GEN_SEQUENTIAL_RW)
+        # a refill launch lasts as long as its slowest board (~0.4 ms at 16x16/10) however few rows
+        # it generates: few, large refills, every entry requested two episodes ahead
+        return ops.GeneratorSpec(nat.GEN_SEQUENTIAL_RW, refill={"every": 48, "depth": 2, "adaptive": True})

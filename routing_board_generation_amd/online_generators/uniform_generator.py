@@ -63,4 +63,5 @@ class UniformRandomGenerator(Generator):
     def native_spec(self):
         from .. import _native as nat
 
-        return ops.GeneratorSpec(nat.GEN_UNIFORM)
+        # drawing 2N cells costs less than copying a stash row: no stash (330 vs 323 M env-steps/s)
+        return ops.GeneratorSpec(nat.GEN_UNIFORM, refill={"every": 0})

@@ -3,6 +3,7 @@
 PyTorch is used for device memory and streams only; every value below is produced by the HIP
 kernels of csrc/prw_kernels.hip.  All functions are batched ([B, ...]) and asynchronous.
 """
+import contextlib
 import ctypes as C
 from typing import Dict, Optional
 
@@ -515,6 +516,7 @@ def alloc_stash(B: int, m: int, N: int, device, depth: int = 1) -> dict:
             "ready_at": torch.zeros((R,), dtype=torch.int32, device=device),
             "refill_key": torch.zeros((R, 2), dtype=torch.uint32, device=device),
             "hits": torch.zeros((B,), dtype=torch.int32, device=device),
+            "misses": torch.zeros((B,), dtype=torch.int32, device=device),
             "depth": depth}
 
 
@@ -526,8 +528,11 @@ def _stash_struct(stash: dict, B: int, m: int, N: int) -> nat.Stash:
     _check(stash["ready_at"], torch.int32, (R,), "stash.ready_at")
     _check(stash["refill_key"], torch.uint32, (R, 2), "stash.refill_key")
     _check(stash["hits"], torch.int32, (B,), "stash.hits")
+    misses = stash.get("misses")
+    if misses is not None:
+        _check(misses, torch.int32, (B,), "stash.misses")
     return nat.Stash(nxt, stash["tag"].data_ptr(), stash["ready_at"].data_ptr(),
-                     stash["refill_key"].data_ptr(), stash["hits"].data_ptr(), depth)
+                     stash["refill_key"].data_ptr(), stash["hits"].data_ptr(), _ptr(misses), depth)
 
 
 def connector_reset_prefetch(keys: torch.Tensor, m: int, N: int, stash: dict, tick: int,
@@ -591,18 +596,31 @@ class EpochStash:
     of epoch e + 2 (one stream event per epoch); entries are usable from tick K * (e + 2) on."""
 
     def __init__(self, B: int, m: int, N: int, device, every: int, serial: bool = True,
-                 depth: int = 1, gen: Optional[GeneratorSpec] = None) -> None:
+                 depth: int = 1, gen: Optional[GeneratorSpec] = None,
+                 adaptive: bool = False) -> None:
         """depth=2: two slots per env, every entry requested a whole episode before it is needed
         (include/rbg_prw.h::rbg_stash) -- for launches of many steps (connector_rollout).
-        gen: the generator whose producer refills the stash (None = ParallelRandomWalk)."""
+        gen: the generator whose producer refills the stash (None = ParallelRandomWalk).
+        adaptive (serial only): watch the stash's miss counter and refill more often when
+        episodes turn out shorter than the refill period -- a miss runs the generator inside the
+        step launch, which for SequentialRandomWalk / SeedExtension stalls that launch for
+        0.1-1 ms.  The period only moves between `every` / 8 and `every`; results never depend
+        on it.  The counter travels to pinned host memory asynchronously (no synchronisation:
+        a decision may lag by one refill)."""
         self.B, self.m, self.N, self.device = B, m, N, device
         self.gen, self._g = gen, _gen_ref(gen)
-        self.K = max(1, int(every))
+        self.K = self.K0 = max(1, int(every))
         self.serial = bool(serial)
         self.tick = 0
+        self._refill_after = self.K - 1  # serial: the launch tick behind which the next refill goes
         self.stash = alloc_stash(B, m, N, device, depth)
         self.struct = _stash_struct(self.stash, B, m, N)
         self._lib = nat.lib()
+        self.adaptive = bool(adaptive) and self.serial
+        if self.adaptive:
+            self._miss_dev = torch.zeros((1,), dtype=torch.int64, device=device)
+            self._miss_host = torch.zeros((1,), dtype=torch.int64).pin_memory()
+            self._miss_seen, self._calm = 0, 0
         if not self.serial:
             # consecutive refills may overlap each other (each keeps only a few waves busy)
             self._sides = [torch.cuda.Stream(device=device) for _ in range(2)]
@@ -611,8 +629,10 @@ class EpochStash:
 
     def ready_delay(self) -> int:
         """Ticks from the current launch to the first one that may use what it requests."""
+        if self.serial:
+            return self._refill_after + 1 - self.tick
         K = self.K
-        return K * (self.tick // K + (1 if self.serial else 2)) - self.tick
+        return K * (self.tick // K + 2) - self.tick
 
     def before_launch(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Right before a reset/step launch on `stream` (default: torch's current stream)."""
@@ -622,26 +642,45 @@ class EpochStash:
         if self.tick % K == 0 and e >= 2:  # first launch of epoch e needs the refill of epoch e-2
             (stream or torch.cuda.current_stream(self.device)).wait_event(self._done[(e - 2) % 4])
 
+    def _adapt(self, stream: Optional[torch.cuda.Stream]) -> None:
+        """Halve the period while misses keep coming, let it grow back after four calm refills."""
+        seen = int(self._miss_host[0])  # whatever has arrived (no synchronisation)
+        if seen - self._miss_seen > self.B // 64:
+            self.K, self._calm = max(self.K0 // 8, 1, self.K // 2), 0
+        elif seen == self._miss_seen:
+            self._calm += 1
+            if self._calm >= 4 and self.K < self.K0:
+                self.K, self._calm = min(self.K0, self.K * 2), 0
+        self._miss_seen = seen
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            torch.sum(self.stash["misses"], dim=0, keepdim=True, out=self._miss_dev)
+            self._miss_host.copy_(self._miss_dev, non_blocking=True)
+
     def after_launch(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Right after it: the last launch of an epoch queues the refill."""
-        K, e = self.K, self.tick // self.K
-        if self.tick % K == K - 1:
-            if self.serial:
+        if self.serial:
+            if self.tick == self._refill_after:
                 sp = C.c_void_p(stream.cuda_stream) if stream is not None else _stream(self.device)
                 nat.check(self._lib.rbg_stash_refill_gen(self._g, self.B, self.m, self.N,
                                                          C.byref(self.struct), sp),
                           "rbg_stash_refill")
-            else:
-                stream = stream or torch.cuda.current_stream(self.device)
-                side = self._sides[e % 2]
-                ev = self._launched[e % 4]
-                ev.record(stream)
-                side.wait_event(ev)
-                nat.check(self._lib.rbg_stash_refill_gen(self._g, self.B, self.m, self.N,
-                                                         C.byref(self.struct),
-                                                         C.c_void_p(side.cuda_stream)),
-                          "rbg_stash_refill")
-                self._done[e % 4].record(side)
+                if self.adaptive:
+                    self._adapt(stream)
+                self._refill_after = self.tick + self.K
+            self.tick += 1
+            return
+        K, e = self.K, self.tick // self.K
+        if self.tick % K == K - 1:
+            stream = stream or torch.cuda.current_stream(self.device)
+            side = self._sides[e % 2]
+            ev = self._launched[e % 4]
+            ev.record(stream)
+            side.wait_event(ev)
+            nat.check(self._lib.rbg_stash_refill_gen(self._g, self.B, self.m, self.N,
+                                                     C.byref(self.struct),
+                                                     C.c_void_p(side.cuda_stream)),
+                      "rbg_stash_refill")
+            self._done[e % 4].record(side)
         self.tick += 1
 
     def drain(self, stream: Optional[torch.cuda.Stream] = None) -> None:

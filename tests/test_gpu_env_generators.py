@@ -221,3 +221,34 @@ def test_fused_random_rollout_for_every_generator(rbg, oracle, name, prefetch, r
             assert (to_np(stats["episodes"]) == episodes).all()
             assert_dicts_equal(timestep_to_np(last), ets, f"{name} launch {launch} last timestep.")
         t0 += n_steps
+
+
+def test_adaptive_refill_period_follows_short_episodes(rbg, oracle):
+    """The generator's default stash schedule refills every 48 steps, two episodes ahead; when
+    episodes are shorter than that (here 4 steps) resets miss the stash and run the generator
+    inside the step launch.  The session watches the miss counter and refills more often --
+    without any effect on the results (compared with the oracle throughout)."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, tl, steps = 10, 4, 48, 4, 260
+    gen, gen_fn = make_pair(rbg, oracle, "online_seq_rw", m, N)
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl))  # default schedule
+    keys, akeys = _keys(rbg, 71, B), _keys(rbg, 72, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
+    (sess,) = env.unwrapped._sessions.values()
+    assert sess.epochs.adaptive and sess.epochs.K == 48
+    periods = []
+    for t in range(steps):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        state, ts = env.step(state, action)
+        ets = oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl)
+        assert_dicts_equal(state_to_np(state), est, f"step {t} state.")
+        assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
+        periods.append(sess.epochs.K)
+    assert min(periods) <= 12, periods[::20]
+    misses = int(to_np(sess.epochs.stash["misses"]).sum())
+    hits = int(to_np(sess.epochs.stash["hits"]).sum())
+    assert misses > 0 and hits > misses, (hits, misses)
+    sess.drain()
