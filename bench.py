@@ -237,13 +237,19 @@ def rehearse_launch(args) -> None:
     lo, hi = sharding.shard_bounds(BATCH_PER_GPU * world, rank, world)
     if dist.is_initialized():
         dist.barrier()
+    launch_ms = 0.03 + 0.01 * rank  # stands in for this rank's event-timed launch duration
     red = sharding.all_reduce_metrics({"boards": float((hi - lo) * args.steps),
-                                       "elapsed_s": 1.0 + rank})
+                                       "elapsed_s": 1.0 + rank, "launch_ms_max": launch_ms,
+                                       "neg_launch_ms_min": -launch_ms})
+    coll = sharding.collective_info()
     if rank == 0:
         print(json.dumps({"metric": "boards_per_sec", "value": None, "unit": "boards/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "rehearsal": True, "boards": red["boards"],
-                          "elapsed_s_max_over_ranks": red["elapsed_s"], "scaling": "weak"}),
+                          "elapsed_s_max_over_ranks": red["elapsed_s"], "scaling": "weak",
+                          "launch_ms_over_ranks": {"min": -red["neg_launch_ms_min"],
+                                                   "max": red["launch_ms_max"]},
+                          "collective": coll}),
               flush=True)
     if dist.is_initialized():
         dist.barrier()
@@ -321,6 +327,64 @@ def cpu_rate(fn, units):
     return units / (time.perf_counter() - t0)
 
 
+GENERATION_TYPES = ("online_parallel_rw", "online_uniform", "online_seq_rw", "online_random_seed",
+                    "offline_parallel_rw", "offline_seed_extension")
+
+
+def env_steps_by_generator(keys, m, N, steps, close=None):
+    """Connector.step for every generation_type of the reference's setup_train.py:112-152 (the
+    policy inside the step launch, auto-reset on, each generator's default next-episode-stash
+    schedule): env-steps/s per GPU.  Returns {generation_type: row}."""
+    import torch
+
+    from routing_board_generation_amd import ops
+    from routing_board_generation_amd.interface.board_generator_interface import make_online_generator
+
+    dev, B = keys.device, keys.shape[0]
+    rows = {}
+    for name in GENERATION_TYPES:
+        kw = {}
+        if name.startswith("offline"):  # cfg.env.seed_extension.* (connector.yaml), 10 000 boards
+            kw = dict(randomness=0.0, two_sided=True, extension_iterations=1, extension_steps=1e23,
+                      number_of_boards=10000)
+        gen = make_online_generator(name, m, N, **kw).native_spec()
+        sched = {"every": 16, "depth": 1, **gen.refill}
+        st, ts = ops.alloc_state(B, m, N, dev), ops.alloc_timestep(B, m, N, dev)
+        loop = ops.StepLoop(st, ts, keys, refill_every=sched["every"], fuse_policy=True, gen=gen,
+                            stash_depth=sched["depth"])
+        loop.reset(keys)
+        warm = max(60, 2 * sched["every"])
+        for t in range(warm):
+            loop.step(t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        if sched["every"]:
+            loop.stash["hits"].zero_()
+            loop.stash["misses"].zero_()
+        t0 = time.perf_counter()
+        e0.record()
+        for t in range(warm, warm + steps):
+            loop.step(t)
+        e1.record()
+        el = close(t0) if close else None
+        torch.cuda.synchronize(dev)
+        loop.drain()
+        us = e0.elapsed_time(e1) / steps * 1e3
+        rows[name] = {"us_per_step": us, "env_steps_per_s": B / us * 1e6,
+                      "stash": ({"refill_every": sched["every"], "slots_per_env": sched["depth"],
+                                 "hits": int(loop.stash["hits"].sum().item()),
+                                 "misses": int(loop.stash["misses"].sum().item())}
+                                if sched["every"] else "none (the generator runs inside the step "
+                                                       "launch of the envs that restart)")}
+        if el is not None:
+            rows[name]["host_wall_us_per_step"] = el / steps * 1e6
+    base = rows["online_parallel_rw"]["us_per_step"]
+    for r in rows.values():
+        r["vs_online_parallel_rw"] = r["us_per_step"] / base
+    return rows
+
+
+
 def all_configs():
     """Every BASELINE.json config on one GPU, each with the CPU port timed beside it (the
     cpu_baseline leg applied to the other configs; `--all-configs`, not the driver's line)."""
@@ -358,6 +422,8 @@ def all_configs():
     gen_row("C1 ParallelRandomWalk 8x8/5 B=1", 8, 5, 1)
     gen_row("C2 ParallelRandomWalk 16x16/10 B=4096", 16, 10, 4096)
     gen_row("C4 ParallelRandomWalk 32x32/20 B=4096 (one GPU's shard of 32768)", 32, 20, 4096)
+    gen_row("C4 ParallelRandomWalk 32x32/20 B=32768 (the global batch in one launch on one GPU)",
+            32, 20, 32768)
     gen_row("C5 SequentialRandomWalk 16x16/10 B=4096", 16, 10, 4096, kind="seq")
     gen_row("C2 shape on the opt-in Philox stream 16x16/10 B=4096", 16, 10, 4096, kind="philox")
     gen_row("C2 shape on the opt-in Philox stream 16x16/10 B=65536", 16, 10, 65536, kind="philox")
@@ -397,6 +463,10 @@ def all_configs():
 
     rows.append({"config": "C3 CPU port (oracle, per-step)", "cpu_threads": threads,
                  "env_steps_per_s": cpu_rate(cpu_steps, B * 10)})
+    # C3's shape for every generator the reference couples to Connector (setup_train.py:112-152)
+    for name, r in env_steps_by_generator(keys, m, N, 480).items():
+        rows.append({"config": f"C3 Connector.step 16x16/10 B=4096, generation_type={name} "
+                               "(policy inside the step launch, obs written, auto-reset)", **r})
     print(json.dumps(rows, indent=1))
 
 
@@ -515,6 +585,19 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def close(t_start):
+        """End of a timed region.  The clock is read when THIS rank's work is complete (a local
+        synchronize); the barrier that keeps the ranks in step comes after the reading, so no
+        collective sits inside anybody's interval.  The per-rank times are MAX-reduced later
+        (sharding.all_reduce_metrics): the job is as slow as its slowest rank."""
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t_start
+        if dist.is_initialized():
+            dist.barrier()
+        return el
+
+    collective = sharding.collective_info(dev)
+
     if dist.is_initialized():  # the first collective pays communicator setup: keep it out of the timed region
         sharding.all_reduce_metrics({"boards": 0.0}, device=dev)
 
@@ -555,14 +638,14 @@ def main() -> None:
     for _ in range(args.steps):
         step()
     ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = close(t0)
     kernel_avg_ms = ev0.elapsed_time(ev1) / args.steps
 
     iters = out["iters"]
     metrics = sharding.all_reduce_metrics({
         "boards": float(B * args.steps), "iters": float(iters.sum().item()),
-        "max_iters": float(iters.max().item()), "elapsed_s": elapsed}, device=dev)
+        "max_iters": float(iters.max().item()), "elapsed_s": elapsed,
+        "launch_ms_max": kernel_avg_ms, "neg_launch_ms_min": -kernel_avg_ms}, device=dev)
     total_elapsed = metrics["elapsed_s"]  # max over ranks
     value = metrics["boards"] / total_elapsed
 
@@ -616,7 +699,7 @@ def main() -> None:
         for _ in range(p_steps):
             ops.prw_generate_philox(keys, m, N, out=p_out)
         pe1.record()
-        barrier()
+        close(time.perf_counter())
         p_ms = pe0.elapsed_time(pe1) / p_steps
         philox = {"value_per_gpu": B / (p_ms * 1e-3), "unit": "boards/s", "ms_per_step": p_ms,
                   "steps": p_steps,
@@ -654,9 +737,8 @@ def main() -> None:
         barrier()
         t0 = time.perf_counter()
         run_pipelined(args.steps)
-        barrier()
         pm = sharding.all_reduce_metrics({"boards": float(B * args.steps),
-                                          "elapsed_s": time.perf_counter() - t0}, device=dev)
+                                          "elapsed_s": close(t0)}, device=dev)
         pipelined = {"streams": n_streams, "value": pm["boards"] / pm["elapsed_s"], "unit": "boards/s",
                      "ms_per_step": pm["elapsed_s"] / args.steps * 1e3,
                      "note": "the same steps with three batches of 4096 in flight on three HIP streams "
@@ -693,8 +775,7 @@ def main() -> None:
             for t in range(30, 30 + args.env_steps):
                 loop.step(t)
             se1.record()
-            barrier()
-            el = time.perf_counter() - t1
+            el = close(t1)
             loop.drain()
             em = sharding.all_reduce_metrics({"env_steps": float(B * args.env_steps),
                                               "elapsed_s": el}, device=dev)
@@ -707,17 +788,14 @@ def main() -> None:
                 env = rbg.MultiToSingleWrapper(env)
             env = rbg.VmapAutoResetWrapper(env, prefetch=prefetch)
             state, ts = env.reset(keys)
-            act = torch.empty((B, N), dtype=torch.int32, device=dev)
+            policy = ops.RandomPolicy(keys, N)  # the acting side of the loop: one launch per step
             for t in range(30):
-                state, ts = env.step(state, ops.random_actions(keys, t, ts.observation.action_mask,
-                                                               out=act))
+                state, ts = env.step(state, policy(t, ts.observation.action_mask))
             barrier()
             t1 = time.perf_counter()
             for t in range(30, 30 + args.env_steps):
-                state, ts = env.step(state, ops.random_actions(keys, t, ts.observation.action_mask,
-                                                               out=act))
-            barrier()
-            el = time.perf_counter() - t1
+                state, ts = env.step(state, policy(t, ts.observation.action_mask))
+            el = close(t1)
             for sess in env.unwrapped._sessions.values():
                 sess.drain()
             em = sharding.all_reduce_metrics({"env_steps": float(B * args.env_steps),
@@ -800,6 +878,7 @@ def main() -> None:
                        "State/TimeStep pytrees; functional = fresh output tensors every step, "
                        "donate = State advanced in place + two alternating TimeStep buffers"}
         ach = B * sb / (k_step * 1e-3) / 1e9
+        by_gen = env_steps_by_generator(keys, m, N, max(96, min(args.env_steps, 480)), close)
         best = "prefetch_fused_policy" if v_fus > v_pref else "prefetch"
         env_step = {"metric": "env_steps_per_sec", "value": max(v_pref, v_fus),
                     "value_variant": best, "unit": "env-steps/s",
@@ -815,6 +894,15 @@ def main() -> None:
                     "ms_per_step": {"prefetch": k_pref, "inline_reset": k_inl,
                                     "prefetch_fused_policy": k_fus, "no_auto_reset": k_off},
                     "wrapper_api": api,
+                    "by_generation_type": {
+                        **by_gen,
+                        "note": "the same step for every generator the reference couples to "
+                                "Connector (setup_train.py:112-152), policy inside the step "
+                                "launch: a finished episode takes its successor from the "
+                                "generator's own next-episode stash (or, for Uniform / the "
+                                "offline dataset, draws it inline -- cheaper than a row copy); "
+                                "no env is ever regenerated that did not finish.  Per GPU "
+                                "(rank 0's events)."},
                     "roofline": {"bound": "hbm", "kernel": "connector_step_kernel",
                                  "achieved": ach,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -861,8 +949,7 @@ def main() -> None:
             ops.connector_rollout_record(st, keys, (i + 2) * T_rec, T_rec, state_out=st,
                                          trajectory=traj)
         ce1.record()
-        barrier()
-        c_elapsed = time.perf_counter() - t3
+        c_elapsed = close(t3)
         cm = sharding.all_reduce_metrics({"env_steps": float(B * T_rec * launches),
                                           "elapsed_s": c_elapsed}, device=dev)
         rec_ms = ce0.elapsed_time(ce1) / launches
@@ -915,8 +1002,7 @@ def main() -> None:
                 ops.connector_rollout(st, keys, (i + 2) * args.rollout_steps, args.rollout_steps,
                                       state_out=st, stats=stats, epochs=ep)
             re1.record()
-            barrier()
-            r_elapsed = time.perf_counter() - t2
+            r_elapsed = close(t2)
             rm = sharding.all_reduce_metrics(
                 {"env_steps": float(B * args.rollout_steps * launches),
                  "episodes": float(stats["episodes"].sum().item()), "elapsed_s": r_elapsed},
@@ -952,6 +1038,14 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": total_elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "timing": {"elapsed_s_max_over_ranks": total_elapsed,
+                       "launch_ms_over_ranks": {"min": -metrics["neg_launch_ms_min"],
+                                                "max": metrics["launch_ms_max"]},
+                       "note": "each rank times its own K steps (barrier, clock, K launches, "
+                               "local synchronize, clock) -- no collective inside the interval; "
+                               "value = boards of all ranks / the MAX of those times; "
+                               "launch_ms_over_ranks = HIP-event span / K per rank"},
+            "collective": collective,
             "config": {"workload": "ParallelRandomWalkGenerator 16x16 grid, 10 agents, "
                                    f"batch {BATCH_PER_GPU} per GPU (BASELINE configs[1])",
                        "grid_size": m, "num_agents": N, "batch_per_gpu": B,

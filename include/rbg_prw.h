@@ -423,6 +423,27 @@ int rbg_connector_step_gen(const rbg_generator *generator, int B, int m, int N,
                            const rbg_env_params *params, const rbg_timestep *timestep,
                            const rbg_stash *stash, int tick, int ready_delay, void *stream);
 
+/* rbg_connector_step_gen with its arguments in ONE struct, for hosts whose FFI pays per argument
+ * and per temporary (ctypes: ~0.25 us per argument, ~1.5 us per struct built; at B = 4096 the step
+ * launch itself takes 12 us): a caller keeps one rbg_step_call per env session, rewrites the
+ * pointers that change from step to step -- state_out and timestep are adjacent, 17 consecutive
+ * pointers -- and passes its address.  Same checks, same launch. */
+typedef struct rbg_step_call {
+  const rbg_generator *generator; /* NULL = ParallelRandomWalk */
+  int32_t B, m, N;
+  int32_t tick, ready_delay;
+  uint32_t policy_t;
+  rbg_state state_in;
+  rbg_state state_out;
+  rbg_timestep timestep;
+  const int32_t *action;
+  const uint32_t *policy_keys;
+  rbg_env_params params;
+  const rbg_stash *stash;
+  void *stream;
+} rbg_step_call;
+int rbg_connector_step_call(const rbg_step_call *call);
+
 /* rbg_stash_refill with the generator's own producer: next[r] = generator(split(refill_key[r])[0])
  * for every row with tag[r] != refill_key[r]. */
 int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,

@@ -71,6 +71,15 @@ class EnvParams(C.Structure):
                 ("connected_reward", C.c_float), ("auto_reset", C.c_int32)]
 
 
+class StepCall(C.Structure):
+    """include/rbg_prw.h::rbg_step_call"""
+    _fields_ = [("generator", C.POINTER(Generator)), ("B", C.c_int32), ("m", C.c_int32),
+                ("N", C.c_int32), ("tick", C.c_int32), ("ready_delay", C.c_int32),
+                ("policy_t", C.c_uint32), ("state_in", State), ("state_out", State),
+                ("timestep", Timestep), ("action", C.c_void_p), ("policy_keys", C.c_void_p),
+                ("params", EnvParams), ("stash", C.POINTER(Stash)), ("stream", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/rbg_prw.h one to one
 SIGNATURES = {
     "rbg_abi_version": (C.c_int, []),
@@ -134,6 +143,7 @@ SIGNATURES = {
                                          C.c_void_p, C.c_uint32, C.POINTER(EnvParams),
                                          C.POINTER(Timestep), C.POINTER(Stash), C.c_int, C.c_int,
                                          C.c_void_p]),
+    "rbg_connector_step_call": (C.c_int, [C.POINTER(StepCall)]),
     "rbg_stash_refill_gen": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,
                                        C.POINTER(Stash), C.c_void_p]),
     "rbg_connector_rollout_gen": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,

@@ -101,6 +101,13 @@ class Connector:
         # user-defined Python generator, which takes the generic path (_generic_auto_reset)
         spec = getattr(self._generator, "native_spec", None)
         self._gen = spec() if callable(spec) else None
+        self._hot = None  # (B, device, session) of the last batched call
+
+    def _configure(self, **attrs) -> None:
+        """Wrapper switches (VmapAutoResetWrapper / MultiToSingleWrapper)."""
+        for k, v in attrs.items():
+            setattr(self, "_" + k, v)
+        self._hot = None
 
     @property
     def unwrapped(self) -> "Connector":
@@ -113,6 +120,9 @@ class Connector:
     def _session(self, B: int, device: torch.device) -> ops.ConnectorSession:
         """The launch context of batched reset/step calls (ops.ConnectorSession), one per batch
         size / device / wrapper configuration."""
+        hot = self._hot
+        if hot is not None and hot[0] == B and hot[1] == device:
+            return hot[2]
         fused_reset = self._auto_reset and self._gen is not None
         delay = self._prefetch_delay
         if delay is None:
@@ -129,6 +139,7 @@ class Connector:
                 self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
                 auto_reset=fused_reset, refill_every=delay, donate=self._donate,
                 aggregate=self._aggregate, gen=self._gen)
+        self._hot = (B, device, sess)
         return sess
 
     # ---------------------------------------------------------------------------------- specs

@@ -30,7 +30,7 @@ class MultiToSingleWrapper(_Wrapper):
 
     def __init__(self, env):
         super().__init__(env)
-        env.unwrapped._aggregate = True
+        env.unwrapped._configure(aggregate=True)
 
     def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
         return self._env.reset(key)
@@ -55,11 +55,11 @@ class VmapAutoResetWrapper(_Wrapper):
         "generation" is cheaper than a stash row copy).
         donate=True/False overrides the env's setting (Connector(donate=...))."""
         super().__init__(env)
-        env.unwrapped._auto_reset = True
-        env.unwrapped._prefetch_delay = (0 if not prefetch else
-                                         None if prefetch_delay is None else int(prefetch_delay))
+        env.unwrapped._configure(auto_reset=True,
+                                 prefetch_delay=(0 if not prefetch else None
+                                                 if prefetch_delay is None else int(prefetch_delay)))
         if donate is not None:
-            env.unwrapped._donate = bool(donate)
+            env.unwrapped._configure(donate=bool(donate))
 
     def reset(self, key: torch.Tensor) -> Tuple[State, TimeStep]:
         if key.dim() != 2:

@@ -459,6 +459,13 @@ int rbg_connector_step_prefetch(int B, int m, int N, const rbg_state *state_in,
                                 timestep, stash, tick, ready_delay, stream);
 }
 
+int rbg_connector_step_call(const rbg_step_call *c) {
+  if (!c) return fail(RBG_E_NULL, "rbg_connector_step_call: NULL call");
+  return rbg_connector_step_gen(c->generator, c->B, c->m, c->N, &c->state_in, &c->state_out,
+                                c->action, c->policy_keys, c->policy_t, &c->params, &c->timestep,
+                                c->stash, c->tick, c->ready_delay, c->stream);
+}
+
 int rbg_connector_step_gen(const rbg_generator *generator, int B, int m, int N,
                            const rbg_state *state_in, const rbg_state *state_out,
                            const int32_t *action, const uint32_t *policy_keys, uint32_t policy_t,

@@ -5,8 +5,10 @@ kernels of csrc/prw_kernels.hip.  All functions are batched ([B, ...]) and async
 """
 import contextlib
 import ctypes as C
+import sys
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from . import _native as nat
@@ -793,6 +795,14 @@ class StepLoop:
 
 
 
+class _Chunk:
+    __slots__ = ("tensors", "views", "tbl", "addr", "flat", "storages", "base_ref", "base_use")
+
+
+# use count of a storage (private torch API; without it chunks are never reused)
+_storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
+
+
 class ConnectorSession:
     """Launch context of the allocating (functional) reset / step for one (B, m, N, device) and
     one set of env parameters: what Connector keeps between calls so that a step costs the host
@@ -851,49 +861,112 @@ class ConnectorSession:
             ("discount_max", f32 if aggregate else None, (B,)))  # dtype None: output not wanted
         self.chunk_steps = (max(1, int(chunk_steps)) if chunk_steps else
                             max(1, min(16, (1 << 30) // (4 * B * N * m * m))))
-        self._views, self._bases, self._cursor = None, None, 0
+        self._chunk, self._pool, self._cursor = None, [], 0
+        self.pool_chunks = 3  # chunks kept for reuse (the current one, the one the State fed to
+        #                       the next step still lives in, one spare)
+        # the step launch as ONE struct (include/rbg_prw.h::rbg_step_call): the pointers that change
+        # from step to step are copied in with two memmoves
+        call = self._call = nat.StepCall()
+        if self._g is not None:
+            call.generator = C.pointer(gen.struct)
+        call.B, call.m, call.N = B, m, N
+        call.params = self._p
+        self._call_ref = C.byref(call)
+        self._addr_in = C.addressof(call) + nat.StepCall.state_in.offset
+        self._addr_out = C.addressof(call) + nat.StepCall.state_out.offset
+        assert nat.StepCall.timestep.offset == nat.StepCall.state_out.offset + 48
+        self._step_call = self._lib.rbg_connector_step_call
+        self._raw_stream = torch._C._cuda_getCurrentRawStream
+        idx = torch.device(device).index
+        self._dev_index = idx if idx is not None else torch.cuda.current_device()
+        self._action_shape = torch.Size((B, N))
+
+    def _new_chunk(self):
+        """Memory, views and pointer table of `chunk_steps` steps' outputs."""
+        S, dev = self.chunk_steps, self.device
+        ch = _Chunk()
+        ch.tensors = [None if dt is None else torch.empty((S,) + shape, dtype=dt, device=dev)
+                      for _, dt, shape in self._specs]
+        ch.views = list(zip(*[(None,) * S if c is None else c.unbind(0)
+                              for c in ch.tensors]))  # [step][field]
+        ch.tbl = np.zeros((S, 17), dtype=np.uint64)  # absent field: pointer 0 = NULL
+        steps = np.arange(S, dtype=np.uint64)
+        for j, c in enumerate(ch.tensors):
+            if c is not None:
+                ch.tbl[:, j] = np.uint64(c.data_ptr()) + steps * np.uint64(c.stride(0) * c.element_size())
+        ch.addr = ch.tbl.ctypes.data
+        # what "nobody but this session refers to the chunk" looks like (see _chunk_is_free)
+        ch.flat = [v for step in ch.views for v in step if v is not None]
+        ch.storages = [c.untyped_storage() for c in ch.tensors if c is not None]
+        ch.base_ref = max(map(sys.getrefcount, ch.flat))
+        ch.base_use = [_storage_use_count(st._cdata) for st in ch.storages] \
+            if _storage_use_count else None
+        return ch
+
+    @staticmethod
+    def _chunk_is_free(ch) -> bool:
+        """True when no tensor of the chunk is referenced outside this session: neither one of
+        the views it handed out (Python reference counts) nor anything derived from them (the
+        storages' use counts: slices, reshapes, autograd's saved tensors).  Reusing such a chunk
+        is what torch's caching allocator does with freed blocks -- same stream-ordering
+        contract -- minus 15 allocations and 15 x chunk_steps view constructions."""
+        if ch.base_use is None or max(map(sys.getrefcount, ch.flat)) > ch.base_ref:
+            return False
+        for st, base in zip(ch.storages, ch.base_use):
+            if _storage_use_count(st._cdata) != base:
+                return False
+        return True
 
     def _fresh(self):
-        """(state leaves, nat.State, timestep leaves, nat.Timestep) of the next step's outputs;
-        leaves in STATE_FIELDS / TIMESTEP_FIELDS order."""
+        """(state leaves, timestep leaves, address of the step's 17 output pointers, owner of that
+        memory): rbg_state then rbg_timestep as they lie in rbg_step_call (state_out, timestep);
+        leaves in STATE_FIELDS / TIMESTEP_FIELDS order.  Every step gets memory of its own; a
+        chunk is reused only once nothing outside the session refers to it any more."""
         i = self._cursor
-        if self._views is None or i == self.chunk_steps:
-            S, dev = self.chunk_steps, self.device
-            chunks = [None if dt is None else torch.empty((S,) + shape, dtype=dt, device=dev)
-                      for _, dt, shape in self._specs]
-            self._views = list(zip(*[(None,) * S if c is None else c.unbind(0)
-                                     for c in chunks]))  # [step][field]
-            self._bases = [(0, 0) if c is None else (c.data_ptr(), c[0].numel() * c.element_size())
-                           for c in chunks]  # absent field: pointer 0 = NULL
+        ch = self._chunk
+        if ch is None or i == self.chunk_steps:
+            nxt = None
+            for cand in self._pool:
+                if cand is not ch and self._chunk_is_free(cand):
+                    nxt = cand
+                    break
+            if nxt is None:
+                nxt = self._new_chunk()
+                if len(self._pool) < self.pool_chunks:
+                    self._pool.append(nxt)
+            ch = self._chunk = nxt
             i = 0
         self._cursor = i + 1
-        v = self._views[i]
-        ptrs = [base + i * nbytes for base, nbytes in self._bases]
-        return v[:6], nat.State(*ptrs[:6]), v[6:], nat.Timestep(*ptrs[6:])
+        v = ch.views[i]
+        return v[:6], v[6:], ch.addr + i * 136, ch
 
-    def _outputs(self, in_leaves=None, in_struct=None):
-        """Where a launch writes: fresh memory, or with donate the input State + the ring."""
-        if not self.donate:
-            return self._fresh()
+    def _ring_next(self):
+        """donate: the TimeStep lands in one of two buffer sets used alternately."""
         if self._ring is None:
             self._ring = []
             for _ in range(2):
                 ts = alloc_timestep(self.B, self.m, self.N, self.device, aggregate=self.aggregate)
                 v = tuple(ts.get(f) for f in TIMESTEP_FIELDS)
-                self._ring.append((v, nat.Timestep(*[_ptr(x) for x in v])))
+                row = np.array([_ptr(x) or 0 for x in v], dtype=np.uint64)
+                self._ring.append((v, row, row.ctypes.data))
         self._ring_i ^= 1
-        tv, t = self._ring[self._ring_i]
-        if in_leaves is None:  # reset
-            st = alloc_state(self.B, self.m, self.N, self.device)
-            in_leaves = tuple(st[f] for f in STATE_FIELDS)
-            in_struct = nat.State(*[x.data_ptr() for x in in_leaves])
-        return in_leaves, in_struct, tv, t
+        return self._ring[self._ring_i]
 
     def reset(self, keys: torch.Tensor):
         keys = check_keys(keys)
         if keys.shape[0] != self.B or keys.device != self.agent_ids.device:
             raise ValueError("keys do not match this session's batch size / device")
-        st, s, ts, t = self._outputs()
+        if self.donate:
+            bufs = alloc_state(self.B, self.m, self.N, self.device)
+            st = tuple(bufs[f] for f in STATE_FIELDS)
+            owner = np.array([x.data_ptr() for x in st], dtype=np.uint64)
+            s_addr = owner.ctypes.data
+            ts, _, t_addr = self._ring_next()
+        else:
+            st, ts, s_addr, owner = self._fresh()
+            t_addr = s_addr + 48
+        s, t = nat.State.from_address(s_addr), nat.Timestep.from_address(t_addr)
+        ep_ref, tick, delay = None, 0, 0
         if self.K:
             if self.epochs is not None:
                 self.epochs.drain()
@@ -901,18 +974,17 @@ class ConnectorSession:
             kw.pop("every", None)
             ep = self.epochs = EpochStash(self.B, self.m, self.N, self.device, self.K,
                                           gen=self.gen, **kw)
+            self._call.stash = C.pointer(ep.struct)
             ep.before_launch()
-            rc = self._lib.rbg_connector_reset_gen(
-                self._g, keys.data_ptr(), self.B, self.m, self.N, C.byref(s), C.byref(t),
-                C.byref(ep.struct), ep.tick, ep.ready_delay(), _stream(self.device))
-            ep.after_launch()
-        else:
-            rc = self._lib.rbg_connector_reset_gen(
-                self._g, keys.data_ptr(), self.B, self.m, self.N, C.byref(s), C.byref(t), None,
-                0, 0, _stream(self.device))
+            ep_ref, tick, delay = C.byref(ep.struct), ep.tick, ep.ready_delay()
+        rc = self._lib.rbg_connector_reset_gen(
+            self._g, keys.data_ptr(), self.B, self.m, self.N, C.byref(s), C.byref(t), ep_ref,
+            tick, delay, _stream(self.device))
+        if self.K:
+            self.epochs.after_launch()
         if rc:
             nat.check(rc, "rbg_connector_reset")
-        self._last = (st, s)
+        self._last = (st, s_addr, owner)
         return st, ts
 
     def step(self, leaves, action: torch.Tensor):
@@ -921,28 +993,38 @@ class ConnectorSession:
         if (last is not None and leaves[0] is last[0][0] and leaves[1] is last[0][1]
                 and leaves[2] is last[0][2] and leaves[3] is last[0][3]
                 and leaves[4] is last[0][4] and leaves[5] is last[0][5]):
-            si = last[1]
+            in_addr, in_owner = last[1], last[2]
         else:
             held = {f: x.contiguous() for f, x in zip(STATE_FIELDS, leaves)}  # alive till launch
-            si = _state_struct(held, self.B, self.m, self.N)
+            in_owner = _state_struct(held, self.B, self.m, self.N)
+            in_addr = C.addressof(in_owner)
             leaves = tuple(held[f] for f in STATE_FIELDS)
-        _check(action, torch.int32, (self.B, self.N), "action")
-        st, s, ts, t = self._outputs(leaves, si)
+        if (action.dtype is not torch.int32 or action.shape != self._action_shape
+                or not action.is_cuda or not action.is_contiguous()):
+            _check(action, torch.int32, (self.B, self.N), "action")
+        call = self._call
+        C.memmove(self._addr_in, in_addr, 48)
+        if self.donate:  # the State advances in place
+            st, owner, s_addr = leaves, in_owner, in_addr
+            ts, _, t_addr = self._ring_next()
+            C.memmove(self._addr_out, in_addr, 48)
+            C.memmove(self._addr_out + 48, t_addr, 88)
+        else:
+            st, ts, s_addr, owner = self._fresh()
+            C.memmove(self._addr_out, s_addr, 136)
+        call.action = action.data_ptr()
+        call.stream = self._raw_stream(self._dev_index)
         ep = self.epochs
         if ep is not None:
             ep.before_launch()
-            rc = self._lib.rbg_connector_step_gen(
-                self._g, self.B, self.m, self.N, C.byref(si), C.byref(s), action.data_ptr(), None,
-                0, C.byref(self._p), C.byref(t), C.byref(ep.struct), ep.tick, ep.ready_delay(),
-                _stream(self.device))
+            call.tick, call.ready_delay = ep.tick, ep.ready_delay()
+            rc = self._step_call(self._call_ref)
             ep.after_launch()
         else:
-            rc = self._lib.rbg_connector_step_gen(
-                self._g, self.B, self.m, self.N, C.byref(si), C.byref(s), action.data_ptr(), None,
-                0, C.byref(self._p), C.byref(t), None, 0, 0, _stream(self.device))
+            rc = self._step_call(self._call_ref)
         if rc:
             nat.check(rc, "rbg_connector_step")
-        self._last = (st, s)
+        self._last = (st, s_addr, owner)
         return st, ts
 
     def drain(self) -> None:
@@ -1062,6 +1144,36 @@ def connector_rollout_record(state: StateBufs, policy_keys: torch.Tensor, t0: in
         epochs.after_launch()
     nat.check(rc, "rbg_connector_rollout_record")
     return so, st, traj
+
+
+class RandomPolicy:
+    """The masked-uniform random policy (rbg_random_actions; stands in for [3P] jumanji's
+    RandomAgent) with its launch bound once: `policy(t, action_mask)` -> action int32 [B, N] in a
+    buffer of its own (two, used alternately).  The checked one-off form is random_actions()."""
+
+    def __init__(self, keys: torch.Tensor, num_agents: int) -> None:
+        self.keys = check_keys(keys)
+        self.B, self.N, self.device = keys.shape[0], int(num_agents), keys.device
+        self._out = [torch.empty((self.B, self.N), dtype=torch.int32, device=self.device)
+                     for _ in range(2)]
+        self._i = 0
+        self._fn = nat.lib().rbg_random_actions
+        self._kp = self.keys.data_ptr()
+        self._mask_shape = torch.Size((self.B, self.N, 5))
+        idx = self.device.index
+        self._dev_index = idx if idx is not None else torch.cuda.current_device()
+
+    def __call__(self, t: int, action_mask: torch.Tensor) -> torch.Tensor:
+        if (action_mask.dtype is not torch.bool or action_mask.shape != self._mask_shape
+                or not action_mask.is_contiguous() or action_mask.device != self.device):
+            _check(action_mask, torch.bool, (self.B, self.N, 5), "action_mask")
+        self._i ^= 1
+        out = self._out[self._i]
+        rc = self._fn(self._kp, self.B, self.N, int(t) & 0xFFFFFFFF, action_mask.data_ptr(),
+                      out.data_ptr(), torch._C._cuda_getCurrentRawStream(self._dev_index))
+        if rc:
+            nat.check(rc, "rbg_random_actions")
+        return out
 
 
 def random_actions(keys: torch.Tensor, t: int, action_mask: torch.Tensor,

@@ -20,7 +20,7 @@ from .random import split
 from .types import State, TimeStep
 
 SUM_METRICS = ("boards", "env_steps", "episodes", "num_connections", "total_path_length", "iters")
-MAX_METRICS = ("max_iters", "elapsed_s")
+MAX_METRICS = ("max_iters", "elapsed_s", "launch_ms_max", "neg_launch_ms_min")
 
 
 def init_distributed(backend: str = None, single_device: bool = False,
@@ -74,6 +74,35 @@ def reset_sharded(env, key: torch.Tensor, total_batch_size: int, rank: int,
     acting_keys = split(k3[2], world)
     state, timestep = env.reset(shard_keys(reset_keys, rank, world))
     return state, timestep, acting_keys[rank]
+
+
+def collective_info(device=None, reps: int = 20) -> Dict[str, object]:
+    """What the live process group is and what one metrics all-reduce costs on it: evidence in a
+    benchmark record that RCCL really saw N ranks (backend, world size, microseconds per
+    all-reduce of the metrics vector, host wall-clock with the device synchronised)."""
+    import time
+
+    if not dist.is_initialized():
+        return {"backend": None, "world_size": 1, "all_reduce_us": None}
+    backend = dist.get_backend()
+    if backend != "nccl":
+        device = torch.device("cpu")
+    elif device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    v = torch.zeros((len(SUM_METRICS),), dtype=torch.float64, device=device)
+    for _ in range(3):
+        dist.all_reduce(v)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(v)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    us = (time.perf_counter() - t0) / reps * 1e6
+    return {"backend": backend, "world_size": dist.get_world_size(), "all_reduce_us": us,
+            "vector_bytes": v.numel() * 8, "reps": reps}
 
 
 def all_reduce_metrics(metrics: Dict[str, float], device=None) -> Dict[str, float]:

@@ -27,6 +27,11 @@ def test_bench_gpus_2_launches_itself():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["rehearsal"] is True
     assert line["boards"] == 2 * 4096 * 3          # summed over the two ranks' shards
     assert line["elapsed_s_max_over_ranks"] == 2.0  # max over ranks of (1 + rank)
+    # per-rank launch times are reduced to (min, max); the live group shows in the record
+    assert abs(line["launch_ms_over_ranks"]["min"] - 0.03) < 1e-12
+    assert abs(line["launch_ms_over_ranks"]["max"] - 0.04) < 1e-12
+    coll = line["collective"]
+    assert coll["backend"] == "gloo" and coll["world_size"] == 2 and coll["all_reduce_us"] > 0
 
 
 def test_bench_relays_the_childs_exit_code():
@@ -40,6 +45,7 @@ def test_bench_single_rank_rehearsal_needs_no_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 1 and line["boards"] == 4096 * 2
+    assert line["collective"] == {"backend": None, "world_size": 1, "all_reduce_us": None}
 
 
 def test_bench_reads_each_traffic_figure_from_its_own_profile():

@@ -1066,3 +1066,47 @@ def test_rollout_with_two_slot_stash_equals_plain_rollout(rbg, torch_mod, m, N, 
     # two slots serve at most two resets per env and launch; the rest walk inline
     total_hits = int(ep.stash["hits"].sum().item())
     assert total_hits > (0.6 if tl * 2 >= n_steps else 0.3) * episodes, (total_hits, episodes)
+
+
+def test_output_chunks_are_reused_only_when_unreferenced(rbg, torch_mod):
+    """The functional step hands out fresh memory every step; a chunk of outputs is reused once
+    nothing outside the session refers to it (Python references to the tensors handed out, or
+    anything derived from them).  Tensors a caller keeps -- directly or through a slice -- must
+    never change; a loop that keeps nothing must stop allocating."""
+    from routing_board_generation_amd import ops
+
+    torch = torch_mod
+    m, N, B = 8, 3, 64
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=rbg.ParallelRandomWalkGenerator(m, N),
+                                                 time_limit=6))
+    keys = _keys(rbg, 5, B)
+    state, ts = env.reset(keys)
+    (sess,) = env.unwrapped._sessions.values()
+    sess.chunk_steps = 4  # small chunks: many turn-overs in a short test
+    made = []
+    new_chunk = sess._new_chunk
+    sess._new_chunk = lambda: made.append(1) or new_chunk()
+    policy = ops.RandomPolicy(keys, N)
+    kept = []  # (tensor or slice kept alive, its value when it was returned)
+    for t in range(120):
+        state, ts = env.step(state, policy(t, ts.observation.action_mask))
+        if t % 7 == 0:
+            kept.append((ts.observation.grid, ts.observation.grid.clone()))
+        if t % 11 == 0:
+            kept.append((ts.reward[3:5], ts.reward[3:5].clone()))  # a derived view only
+        if t % 13 == 0:
+            kept.append((state.grid, state.grid.clone()))
+    torch.cuda.synchronize()
+    for held, snapshot in kept:
+        assert torch.equal(held, snapshot), "a tensor the caller still holds was overwritten"
+    n_with_refs = len(made)
+    # now a loop that keeps nothing: after the pool has turned over no chunk is allocated any more
+    kept.clear()
+    del held, snapshot
+    for t in range(120, 160):
+        state, ts = env.step(state, policy(t, ts.observation.action_mask))
+    made.clear()
+    for t in range(160, 260):
+        state, ts = env.step(state, policy(t, ts.observation.action_mask))
+    assert len(made) == 0 and n_with_refs > 3, (len(made), n_with_refs)
+    sess.drain()

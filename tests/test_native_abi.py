@@ -38,10 +38,32 @@ def test_version_and_abi(native):
     assert b"gfx950" in lib.rbg_version()
 
 
-def test_struct_layouts_match_header(native):
+def test_struct_layouts_match_header(native, tmp_path):
     assert C.sizeof(native.State) == 6 * C.sizeof(C.c_void_p)
     assert C.sizeof(native.Timestep) == 11 * C.sizeof(C.c_void_p)
     assert C.sizeof(native.EnvParams) == 16
+    # every struct of the header as the C compiler lays it out against the ctypes mirror
+    import subprocess
+
+    structs = {"rbg_state": native.State, "rbg_timestep": native.Timestep,
+               "rbg_env_params": native.EnvParams, "rbg_stash": native.Stash,
+               "rbg_rollout_stats": native.RolloutStats, "rbg_generator": native.Generator,
+               "rbg_step_call": native.StepCall}
+    lines = []
+    for cname, ct in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rbg_prw.h"\nint main(void){'
+                   + "".join(lines) + "return 0;}")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
 
 
 def test_argument_errors_do_not_need_a_gpu(native):
