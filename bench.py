@@ -760,11 +760,15 @@ def main() -> None:
     if args.env_steps > 0:
         sb = env_step_bytes(m, N)
 
-        def run_loop(refill_every, fuse, auto_reset=True):
+        def run_loop(refill_every, fuse, auto_reset=True, groups=1):
             st = ops.alloc_state(B, m, N, dev)
             ts = ops.alloc_timestep(B, m, N, dev)
-            loop = ops.StepLoop(st, ts, keys, refill_every=refill_every, fuse_policy=fuse,
-                                auto_reset=auto_reset)
+            if groups > 1:  # half-batches on streams of their own (ops.GroupedStepLoop)
+                loop = ops.GroupedStepLoop(st, ts, keys, groups=groups, refill_every=refill_every,
+                                           fuse_policy=fuse, auto_reset=auto_reset)
+            else:
+                loop = ops.StepLoop(st, ts, keys, refill_every=refill_every, fuse_policy=fuse,
+                                    auto_reset=auto_reset)
             loop.reset(keys)
             for t in range(30):
                 loop.step(t)
@@ -774,6 +778,8 @@ def main() -> None:
             se0.record()
             for t in range(30, 30 + args.env_steps):
                 loop.step(t)
+            if groups > 1:
+                loop.join()
             se1.record()
             el = close(t1)
             loop.drain()
@@ -870,6 +876,7 @@ def main() -> None:
         k_step, k_span = step_kernel_ms(16)
         v_inl, k_inl = run_loop(0, False)
         v_fus, k_fus = run_loop(16, True)
+        v_grp, k_grp = run_loop(16, True, groups=2)
         v_off, k_off = run_loop(0, False, auto_reset=False)
         api = {"functional": run_api(False, False), "functional_prefetch": run_api(True, False),
                "donate_prefetch": run_api(True, True),
@@ -890,9 +897,16 @@ def main() -> None:
                               "step launch from the state's own mask (prefetch_fused_policy: "
                               "rbg_connector_rollout_prefetch with n_steps = 1, bit-identical)",
                     "variants": {"prefetch": v_pref, "inline_reset": v_inl,
-                                 "prefetch_fused_policy": v_fus, "no_auto_reset": v_off},
+                                 "prefetch_fused_policy": v_fus,
+                                 "prefetch_fused_policy_2groups": v_grp, "no_auto_reset": v_off},
                     "ms_per_step": {"prefetch": k_pref, "inline_reset": k_inl,
-                                    "prefetch_fused_policy": k_fus, "no_auto_reset": k_off},
+                                    "prefetch_fused_policy": k_fus,
+                                    "prefetch_fused_policy_2groups": k_grp,
+                                    "no_auto_reset": k_off},
+                    "two_groups_note": "prefetch_fused_policy_2groups = the batch as two groups "
+                                       "of 2048 envs on two HIP streams (ops.GroupedStepLoop): "
+                                       "bit-identical results; reported beside `value`, which "
+                                       "stays the single-stream figure",
                     "wrapper_api": api,
                     "by_generation_type": {
                         **by_gen,

@@ -13,10 +13,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libprw_oracle.so")
+# RBG_ORACLE_LIB: another build of the same sources (the sanitizer build of `make asan-check`)
+_OVERRIDE = os.environ.get("RBG_ORACLE_LIB")
+_LIB_PATH = _OVERRIDE or os.path.join(_HERE, "libprw_oracle.so")
 
 
 def build(force: bool = False) -> str:
+    if _OVERRIDE:
+        return _LIB_PATH
     srcs = [os.path.join(_HERE, f) for f in ("prw_oracle.c", "seed_extension.c", "prw_philox.c", "Makefile")]
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
@@ -393,6 +397,19 @@ def seq_rw_generator_batch(keys, m, N, threads=1):
     if rc != 0:
         raise ValueError("oracle_seq_rw_generator_batch: bad arguments")
     return st, solved, attempts
+
+
+def seq_rw_rounding_audit(keys, m, N, threads=1):
+    """Float32 rounding audit of the integer Gumbel-top-1 rule over the SequentialRandomWalk
+    generator (prw_oracle.c::oracle_seq_rw_rounding_audit) -> dict of per-board int32 arrays."""
+    keys = _u32(keys).reshape(-1, 2)
+    B = keys.shape[0]
+    out = {k: np.zeros((B,), np.int32) for k in ("draws", "differs", "within_4ulp", "min_ulps")}
+    rc = lib().oracle_seq_rw_rounding_audit(_p(keys), B, m, N, *[_p(v) for v in out.values()],
+                                            threads)
+    if rc != 0:
+        raise ValueError("oracle_seq_rw_rounding_audit: bad arguments")
+    return out
 
 
 def randint_vec(key, n, lo, hi):

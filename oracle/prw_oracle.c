@@ -775,7 +775,32 @@ void oracle_random_actions_batch(const uint32_t *keys /*[B][2]*/, int B, int N, 
  * log(-log(u)) could merge two adjacent u into one g and then prefer the lower index; that
  * cannot be reproduced without XLA's exact log and is not attempted -- SURVEY Appendix A.6.)
  * ---------------------------------------------------------------------------------------- */
-static int gumbel_top1(const uint32_t key[2], const uint8_t *valid, int n) {
+/* Rounding audit of that shortcut (oracle_seq_rw_rounding_audit below): per board, how many
+ * draws had >= 2 candidates, in how many of them evaluating jax's float32 formula
+ *   u = max(tiny, bitcast(bits >> 9 | 0x3F800000) - 1);  g = logf(-logf(u));  argmin g, stable
+ * with this libm picks another entry than the integer rule, and in how many the runner-up's g
+ * (with another u) lies within 4 float32 ulps of the winner's (a differently rounded logf --
+ * XLA's is not glibc's -- could then pick it). */
+typedef struct {
+  int32_t draws, differs, within_4ulp, min_ulps;
+} seq_audit_t;
+
+static int32_t float_order(float x) { /* monotone map float -> int */
+  int32_t i;
+  memcpy(&i, &x, sizeof(i));
+  return i < 0 ? (int32_t)0x80000000 - i : i;
+}
+
+static float gumbel_key(uint32_t bits) {
+  uint32_t w = (bits >> 9) | 0x3F800000u;
+  float f;
+  memcpy(&f, &w, sizeof(f));
+  f -= 1.0f;
+  if (f < 1.17549435e-38f) f = 1.17549435e-38f; /* uniform(minval=finfo.tiny) */
+  return logf(-logf(f));
+}
+
+static int gumbel_top1(const uint32_t key[2], const uint8_t *valid, int n, seq_audit_t *audit) {
   uint32_t bits[ORACLE_MAX_CELLS];
   oracle_random_bits(key, n, bits);
   int best = 0, have = 0;
@@ -787,6 +812,32 @@ static int gumbel_top1(const uint32_t key[2], const uint8_t *valid, int n) {
       best = j;
       best_u = u;
       have = 1;
+    }
+  }
+  if (audit && have) {
+    int fbest = -1, others = 0;
+    float gbest = 0.0f;
+    int32_t gap = 0x7FFFFFFF;
+    const float gwin = gumbel_key(bits[best]);
+    for (int j = 0; j < n; ++j) {
+      if (!valid[j]) continue;
+      const float g = gumbel_key(bits[j]);
+      if (fbest < 0 || g < gbest) { /* stable argsort: the first of equal keys */
+        fbest = j;
+        gbest = g;
+      }
+      if (j != best) ++others;
+      if (j != best && (bits[j] >> 9) != best_u) { /* (equal u: equal g under any logf) */
+        int64_t d = (int64_t)float_order(g) - (int64_t)float_order(gwin);
+        if (d < 0) d = -d;
+        if (d < (int64_t)gap) gap = (int32_t)d;
+      }
+    }
+    if (others > 0) {
+      audit->draws += 1;
+      audit->differs += fbest != best;
+      audit->within_4ulp += gap <= 4;
+      if (gap < audit->min_ulps) audit->min_ulps = gap;
     }
   }
   return best; /* all-invalid: argsort of all-inf keeps index 0 */
@@ -801,7 +852,7 @@ static void seq_available(const int32_t *grid, int m, int32_t cell, int32_t *ava
 
 /* add_agents (:290-320) for one max_length; returns success, fills first/last cell per wire */
 static int seq_add_agents(const uint32_t key_in[2], int m, int N, int max_length, int32_t *grid,
-                          int32_t *first /*[N]*/, int32_t *last /*[N]*/) {
+                          int32_t *first /*[N]*/, int32_t *last /*[N]*/, seq_audit_t *audit) {
   int n = m * m, success = 1;
   uint32_t key[2] = {key_in[0], key_in[1]};
   memset(grid, 0, sizeof(int32_t) * (size_t)n);
@@ -822,7 +873,7 @@ static int seq_add_agents(const uint32_t key_in[2], int m, int N, int max_length
       success = 0;
       continue;
     }
-    int cell = gumbel_top1(&ps[2], valid, n);
+    int cell = gumbel_top1(&ps[2], valid, n, audit);
     grid[cell] = 3 * w + POSITION;
     first[w] = last[w] = cell;
     int moved = 0;
@@ -841,7 +892,7 @@ static int seq_add_agents(const uint32_t key_in[2], int m, int N, int max_length
       oracle_split(key, 2, ss); /* one_step: key, subkey = split(key) */
       key[0] = ss[0];
       key[1] = ss[1];
-      int pick = gumbel_top1(&ss[2], ok, m + 1);
+      int pick = gumbel_top1(&ss[2], ok, m + 1, audit);
       int32_t nxt = avail[pick];
       grid[nxt] = 3 * w + TARGET;
       grid[last[w]] = 3 * w + PATH;
@@ -855,12 +906,20 @@ static int seq_add_agents(const uint32_t key_in[2], int m, int N, int max_length
 
 /* generate (:322-393) + generate_starts_ends (:395-431).  Returns the number of attempts
  * (1 .. 2m), or 0 when every attempt failed (board all zero, starts = ends = (0, 0)). */
+static int seq_rw_generate(const uint32_t key[2], int m, int N, int32_t *board,
+                           int32_t *starts, int32_t *ends, seq_audit_t *audit);
+
 int oracle_seq_rw_generate(const uint32_t key[2], int m, int N, int32_t *board /*[m][m]*/,
                            int32_t *starts /*[N][2]*/, int32_t *ends /*[N][2]*/) {
+  return seq_rw_generate(key, m, N, board, starts, ends, NULL);
+}
+
+static int seq_rw_generate(const uint32_t key[2], int m, int N, int32_t *board,
+                           int32_t *starts, int32_t *ends, seq_audit_t *audit) {
   int32_t first[ORACLE_MAX_AGENTS], last[ORACLE_MAX_AGENTS];
   int start_max = 2 * m;
   for (int i = 1; i <= start_max; ++i) {
-    if (seq_add_agents(key, m, N, start_max - i, board, first, last)) {
+    if (seq_add_agents(key, m, N, start_max - i, board, first, last, audit)) {
       for (int w = 0; w < N; ++w) {
         starts[2 * w] = first[w] / m;
         starts[2 * w + 1] = first[w] % m;
@@ -901,6 +960,29 @@ int oracle_seq_rw_generator_batch(const uint32_t *keys, int B, int m, int N, int
     st.key[0] = ks[0];
     st.key[1] = ks[1];
     if (attempts) attempts[b] = tries;
+  }
+  return 0;
+}
+
+/* The float32 rounding audit of gumbel_top1 over SequentialRandomWalkGenerator.__call__ of B keys
+ * (every attempt of every board, as the reference runs them): per board the number of draws with
+ * >= 2 candidates, of draws where this libm's float32 evaluation of jax's formula picks another
+ * entry, of draws whose runner-up is within 4 ulps, and the smallest gap in ulps. */
+int oracle_seq_rw_rounding_audit(const uint32_t *keys, int B, int m, int N, int32_t *draws,
+                                 int32_t *differs, int32_t *within_4ulp, int32_t *min_ulps,
+                                 int threads) {
+  if (N > ORACLE_MAX_AGENTS || m * m > ORACLE_MAX_CELLS || m + 1 > 64) return -1;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+  for (int b = 0; b < B; ++b) {
+    uint32_t ks[4];
+    int32_t board[ORACLE_MAX_CELLS], st[2 * ORACLE_MAX_AGENTS], en[2 * ORACLE_MAX_AGENTS];
+    seq_audit_t a = {0, 0, 0, 0x7FFFFFFF};
+    oracle_split(keys + 2 * b, 2, ks);
+    seq_rw_generate(&ks[0], m, N, board, st, en, &a);
+    draws[b] = a.draws;
+    differs[b] = a.differs;
+    within_4ulp[b] = a.within_4ulp;
+    min_ulps[b] = a.min_ulps;
   }
   return 0;
 }

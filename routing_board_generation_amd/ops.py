@@ -734,6 +734,21 @@ class StepLoop:
         if self.K:
             self.stash, self._h = self._epochs.stash, self._epochs.struct
             self._hp = C.byref(self._h)
+        # the step launch as one struct (rbg_step_call): every pointer of this loop is fixed
+        call = self._call = nat.StepCall()
+        if self._g is not None:
+            call.generator = C.pointer(gen.struct)
+        call.B, call.m, call.N = B, m, N
+        call.state_in = call.state_out = self._s
+        call.timestep = self._t
+        call.params = self._p
+        if self.K:
+            call.stash = C.pointer(self._h)
+        call.stream = self._main
+        self._call_ref = C.byref(call)
+        self._step_call = self._lib.rbg_connector_step_call
+        self._keys_ptr, self._action_ptr = self.keys.data_ptr(), self.action.data_ptr()
+        self._mask_ptr = _ptr(timestep.get("action_mask"))
 
     @property
     def tick(self) -> int:
@@ -764,35 +779,91 @@ class StepLoop:
     def step(self, t: int, action: Optional[torch.Tensor] = None) -> None:
         """Policy at global step t, then one auto-resetting env step, in place.  With `action`
         (int32 [B, N], e.g. recorded from an earlier pass) the policy launch is skipped."""
-        lib = self._lib
-        pol_ptr, act_ptr = None, None
+        call = self._call
         if action is not None:
-            act_ptr = _check(action, torch.int32, (self.B, self.N), "action").data_ptr()
+            call.action = _check(action, torch.int32, (self.B, self.N), "action").data_ptr()
+            call.policy_keys = None
         elif self.fuse_policy:  # policy + step in ONE launch
-            pol_ptr = self.keys.data_ptr()
+            call.action, call.policy_keys = None, self._keys_ptr
         else:
-            rc = lib.rbg_random_actions(self.keys.data_ptr(), self.B, self.N, int(t) & 0xFFFFFFFF,
-                                        self.timestep["action_mask"].data_ptr(),
-                                        self.action.data_ptr(), self._main)
+            rc = self._lib.rbg_random_actions(self._keys_ptr, self.B, self.N, int(t) & 0xFFFFFFFF,
+                                              self._mask_ptr, self._action_ptr, self._main)
             if rc:
                 nat.check(rc, "rbg_random_actions")
-            act_ptr = self.action.data_ptr()
-        if self.K:
-            self._before_launch()
-        rc = lib.rbg_connector_step_gen(
-            self._g, self.B, self.m, self.N, C.byref(self._s), C.byref(self._s), act_ptr, pol_ptr,
-            int(t) & 0xFFFFFFFF, C.byref(self._p), C.byref(self._t), self._hp, self.tick,
-            self._ready_delay() if self.K else 0, self._main)
+            call.action, call.policy_keys = self._action_ptr, None
+        call.policy_t = int(t) & 0xFFFFFFFF
+        ep = self._epochs
+        if ep is not None:
+            ep.before_launch(self._main_stream)
+            call.tick, call.ready_delay = ep.tick, ep.ready_delay()
+            rc = self._step_call(self._call_ref)
+            ep.after_launch(self._main_stream)
+        else:
+            rc = self._step_call(self._call_ref)
         if rc:
             nat.check(rc, "rbg_connector_step")
-        if self.K:
-            self._after_launch()
 
     def drain(self) -> None:
         """Make the main stream wait for every refill in flight (before freeing the buffers)."""
         if self.K:
             self._epochs.drain(self._main_stream)
 
+
+
+class GroupedStepLoop:
+    """StepLoop over `groups` contiguous slices of the batch, each on a HIP stream of its own: a
+    group's step t + 1 depends only on its own step t, so one group's per-launch fixed cost
+    (dependent-launch floor, pipeline fill: ~5.7 of the 12 us of a 4096-env step launch,
+    DESIGN.md 4.2) hides behind the other group's store stream.  Same buffers, same results as
+    one StepLoop (tests).  The groups run ahead of torch's current stream: call join() before
+    anything else reads the buffers -- a join costs an event round trip (~20 us), so this shape
+    pays only for loops that read the buffers every many steps (random policy inside the step
+    launch, trajectory statistics)."""
+
+    def __init__(self, state: StateBufs, timestep: TimestepBufs, policy_keys: torch.Tensor,
+                 groups: int = 2, **kw) -> None:
+        B = state["grid"].shape[0]
+        dev = state["grid"].device
+        policy_keys = check_keys(policy_keys)
+        self.B, self.device, self.groups = B, dev, int(groups)
+        self.state, self.timestep = state, timestep
+        base, extra = divmod(B, self.groups)
+        self.bounds, lo = [], 0
+        for g in range(self.groups):
+            hi = lo + base + (1 if g < extra else 0)
+            self.bounds.append((lo, hi))
+            lo = hi
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.groups)]
+        self.loops = []
+        cur = torch.cuda.current_stream(dev)
+        for (lo, hi), st in zip(self.bounds, self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):  # StepLoop binds the stream that is current here
+                self.loops.append(StepLoop({k: v[lo:hi] for k, v in state.items()},
+                                           {k: v[lo:hi] for k, v in timestep.items()},
+                                           policy_keys[lo:hi].contiguous(), **kw))
+
+    def reset(self, keys: torch.Tensor) -> None:
+        keys = check_keys(keys)
+        cur = torch.cuda.current_stream(self.device)
+        for (lo, hi), st, loop in zip(self.bounds, self.streams, self.loops):
+            st.wait_stream(cur)  # the keys were produced on the caller's stream
+            loop.reset(keys[lo:hi].contiguous())
+
+    def step(self, t: int) -> None:
+        for loop in self.loops:
+            loop.step(t)
+
+    def join(self) -> None:
+        """torch's current stream waits for every group's work so far."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def drain(self) -> None:
+        for loop in self.loops:
+            loop.drain()
+        self.join()
 
 
 class _Chunk:

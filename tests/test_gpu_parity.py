@@ -1110,3 +1110,31 @@ def test_output_chunks_are_reused_only_when_unreferenced(rbg, torch_mod):
         state, ts = env.step(state, policy(t, ts.observation.action_mask))
     assert len(made) == 0 and n_with_refs > 3, (len(made), n_with_refs)
     sess.drain()
+
+
+@pytest.mark.parametrize("groups,B", [(2, 256), (3, 100)])
+def test_grouped_step_loop_equals_one_group(rbg, torch_mod, groups, B):
+    """ops.GroupedStepLoop: the batch stepped as contiguous groups on streams of their own gives
+    exactly the buffers of one StepLoop (a group's step depends only on its own state)."""
+    from routing_board_generation_amd import ops
+
+    torch = torch_mod
+    m, N, steps = 16, 10, 70
+    keys, akeys = _keys(rbg, 61, B), _keys(rbg, 62, B)
+    dev = keys.device
+    out = []
+    for g in (1, groups):
+        st, ts = ops.alloc_state(B, m, N, dev), ops.alloc_timestep(B, m, N, dev)
+        kw = dict(time_limit=11, refill_every=5, fuse_policy=True)
+        loop = (ops.StepLoop(st, ts, akeys, **kw) if g == 1
+                else ops.GroupedStepLoop(st, ts, akeys, groups=g, **kw))
+        loop.reset(keys)
+        for t in range(steps):
+            loop.step(t)
+        loop.drain()
+        torch.cuda.synchronize()
+        out.append(({k: v.clone() for k, v in st.items()}, {k: v.clone() for k, v in ts.items()}))
+    for a, b in zip(out[0], out[1]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert int(out[0][0]["step_count"].max()) <= 11
