@@ -151,10 +151,12 @@ def build_microbench() -> str:
     return so
 
 
-def hbm_peaks(dev) -> dict:
+def hbm_peaks(dev, nbytes: int = 1 << 32) -> dict:
     """Measured HBM rates of this GPU (quoted beside the 8 TB/s spec figure): a
     16-B-per-lane copy (read + written bytes) and a write-only fill, plain and non-temporal,
-    1 GiB buffers (far beyond the 256 MiB Infinity Cache); best of the grid sizes tried."""
+    4 GiB buffers = 16x the 256 MiB Infinity Cache (at 1 GiB, round 2's size, a quarter of a
+    buffer can stay on chip between launches and the figures come out 10-25 % higher: reported
+    as `at_1GiB`); best of the grid sizes tried."""
     import ctypes as C
 
     import torch
@@ -162,7 +164,6 @@ def hbm_peaks(dev) -> dict:
     lib = C.CDLL(build_microbench())
     lib.hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     lib.hbm_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
-    nbytes = 1 << 30
     src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -190,9 +191,16 @@ def hbm_peaks(dev) -> dict:
         out["fill" + tag] = rate(lambda b: lib.hbm_fill(dst.data_ptr(), nbytes, nt, b, stream),
                                  nbytes)
     del src, dst
+    torch.cuda.empty_cache()
     out["unit"] = "GB/s"
+    out["buffer_bytes"] = nbytes
     out["note"] = ("tools/microbench/hbm_peak.hip: float4 copy (bytes read + written) and "
-                   "write-only fill over 1 GiB, each wave on contiguous 16 KiB chunks")
+                   f"write-only fill over {nbytes >> 30} GiB buffers, each wave on contiguous "
+                   "16 KiB chunks")
+    if nbytes > (1 << 30):
+        small = hbm_peaks(dev, 1 << 30)
+        out["at_1GiB"] = {k: small[k] for k in ("copy", "fill", "copy_nontemporal",
+                                                "fill_nontemporal")}
     return out
 
 
@@ -498,12 +506,16 @@ def pure_stream(rbg, ops, torch, dev, m, N, sb, Bs, copy_gbs=None):
             "peak_measured_copy": copy_gbs, "frac_of_measured_copy": p_ach / copy_gbs,
             **({"peak_measured": peaks} if peaks else {}),
             "algorithmic_bytes_per_launch": Bs * sb,
-            "traffic": measured_traffic("connector_step_kernel", Bs, "_stream", 65536),
+            "traffic": measured_traffic("connector_step_kernel", Bs,
+                                        "_stream262k" if Bs == 262144 else "_stream", Bs),
+            "working_set_bytes": Bs * sb,
+            "working_set_over_infinity_cache": Bs * sb / (256 * 2 ** 20),
             "note": "connector_step_kernel, NOOP actions (no terminations), working set "
-                    f"{Bs * sb / 1e6:.0f} MB > 256 MiB Infinity Cache; 92 % of its bytes are "
-                    "write-once non-temporal stores, which is why it can exceed the measured "
-                    "COPY rate (a copy reads as many bytes as it writes); `bench.py --mode "
-                    "stream` runs only this and its WRITE_SIZE pass is in profiles/"}
+                    f"{Bs * sb / 1e6:.0f} MB = {Bs * sb / (256 * 2 ** 20):.1f}x the 256 MiB "
+                    "Infinity Cache; 92 % of its bytes are write-once non-temporal stores, which "
+                    "is why it can exceed the measured COPY rate (a copy reads as many bytes as "
+                    "it writes); `bench.py --mode stream [--stream-batch B]` runs only this and "
+                    "its WRITE_SIZE pass is in profiles/"}
 
 
 def main() -> None:
@@ -524,6 +536,10 @@ def main() -> None:
                          "one-GPU box exercises RCCL init / barrier / all-reduce")
     ap.add_argument("--stream-batch", type=int, default=65536,
                     help="batch of the pure-step HBM streaming check (0 = skip)")
+    ap.add_argument("--stream-batch-large", type=int, default=262144,
+                    help="second, larger batch of that check in the default run: a working set "
+                         "13x the Infinity Cache (3.4 GB), so that nothing of it can be "
+                         "absorbed on chip between launches (0 = skip)")
     ap.add_argument("--rollout-steps", type=int, default=50,
                     help="env steps per launch of the fused random-policy rollout (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
@@ -941,8 +957,21 @@ def main() -> None:
         # Infinity Cache): how close connector_kernel gets to the HBM roofline when neither resets
         # nor the host's launch rate limit it
         if rank == 0 and args.stream_batch > 0:
-            env_step["pure_step_stream"] = pure_stream(rbg, ops, torch, dev, m, N, sb,
-                                                       args.stream_batch, copy_gbs)
+            small = pure_stream(rbg, ops, torch, dev, m, N, sb, args.stream_batch, copy_gbs)
+            env_step["pure_step_stream"] = small
+            if args.stream_batch_large > args.stream_batch:
+                # the HBM figure proper: FETCH/WRITE_SIZE count Infinity-Cache hits too, and 256 MiB
+                # of an 851 MB working set can stay on chip from launch to launch; at 13x the
+                # cache the rate below is what HBM itself sustains, and `frac` is quoted on it
+                torch.cuda.empty_cache()
+                large = pure_stream(rbg, ops, torch, dev, m, N, sb, args.stream_batch_large,
+                                    copy_gbs)
+                torch.cuda.empty_cache()
+                env_step["pure_step_stream"] = {
+                    **large, "which_is_hbm": "this row (working set 13x the Infinity Cache); "
+                                             "smaller_working_set may include MALL absorption "
+                                             "(3.3x the cache: up to 30 % of it can stay on chip)",
+                    "smaller_working_set": small}
 
     # ---------------------------------------------------------------- secondary: fused rollout
     def recorded_rollout(launches):

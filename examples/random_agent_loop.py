@@ -31,7 +31,7 @@ def main() -> None:
     ap.add_argument("--n-steps", type=int, default=50)
     ap.add_argument("--one-launch-per-epoch", action="store_true",
                     help="collect the epoch's trajectory with ONE kernel launch "
-                         "(env.random_rollout(..., record=True)) instead of n-steps env.step calls")
+                         "(env.random_rollout_record(...)) instead of n-steps env.step calls")
     args = ap.parse_args()
 
     rank, local_rank, world = sharding.init_distributed()
@@ -62,7 +62,7 @@ def main() -> None:
         if args.one_launch_per_epoch:
             # the same n_steps of RandomAgent + env.step, recorded by one launch: every field of
             # `traj` has a leading time axis [n_steps, B, ...] (what lax.scan stacks in run_epoch)
-            state, actions, traj = env.random_rollout(state, policy_keys, t, args.n_steps, record=True)
+            state, _, actions, traj = env.random_rollout_record(state, policy_keys, t, args.n_steps)
             last = traj.last()
             episodes += last.sum()
             ep_return += traj.reward.sum()

@@ -164,7 +164,11 @@ int rbg_seq_rw_generate(const uint32_t *keys, int B, int m, int N, int split_fir
  * cells); solved_grid, when given, also triggers the final re-routing pass, which no other
  * output can see.  sweeps (nullable) int32 [B] = extension sweeps that changed the board (a
  * board none of whose ends can extend is finished; the reference sweeps it a few more times,
- * until an un-flipped sweep lets its stopping comparison succeed, with no effect on any output).
+ * until an un-flipped sweep lets its stopping comparison succeed, with no effect on any output --
+ * so this is NOT the reference's `step_num`, and max_extension_steps counts these live sweeps).
+ * The sign bit of sweeps[b] is set if a random-direction try loop of board b ran 512 tries
+ * without a valid direction and took the lowest valid one instead (probability < 1e-63 per
+ * extension with jax's stream; a set bit means the board is not the reference's).
  * extension_iterations == -1 (with split_first == 0): return_seeded_board(keys)
  * (seed_extension.py:93-147) -- the keys are the seed keys themselves and nothing is extended.
  * N <= (m / 2)^2 (the candidate seed cells). */

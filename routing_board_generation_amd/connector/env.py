@@ -81,9 +81,15 @@ def _timestep_from_leaves(v) -> TimeStep:
 
 class Connector:
     def __init__(self, generator: Optional[Generator] = None, reward_fn: Optional[DenseRewardFn] = None,
-                 time_limit: int = 50, viewer=None, donate: bool = False) -> None:
+                 time_limit: int = 50, viewer=None, donate: bool = False,
+                 chunk_steps: Optional[int] = None) -> None:
         """donate=True (not in jumanji): batched step() advances the State in place and reuses two
-        TimeStep buffer sets alternately instead of allocating outputs (ops.ConnectorSession)."""
+        TimeStep buffer sets alternately instead of allocating outputs (ops.ConnectorSession).
+        chunk_steps (not in jumanji): batched step() carves its fresh outputs from chunks of this
+        many steps (default: up to 16, at most 1 GiB per field).  A tensor of a returned
+        State / TimeStep that the caller keeps alive keeps its whole chunk alive (and out of
+        reuse): a replay buffer that retains timesteps should .clone() them or pass
+        chunk_steps=1."""
         self._generator = generator or UniformRandomGenerator(grid_size=10, num_agents=5)
         self._reward_fn = reward_fn or DenseRewardFn()
         self.time_limit = time_limit
@@ -94,6 +100,7 @@ class Connector:
         self._prefetch_delay = 0  # VmapAutoResetWrapper(prefetch=True): > 0, or None = the
         #                           generator's own schedule (ops.GeneratorSpec.refill)
         self._donate = bool(donate)
+        self._chunk_steps = chunk_steps
         self._aggregate = False  # switched on by MultiToSingleWrapper
         self._sessions = {}  # (B, device, wrapper + env parameters) -> ops.ConnectorSession
         self._rollout_epochs = {}  # (B, device) -> ops.EpochStash of random_rollout
@@ -138,7 +145,7 @@ class Connector:
                 B, self.grid_size, self.num_agents, device, self.time_limit,
                 self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
                 auto_reset=fused_reset, refill_every=delay, donate=self._donate,
-                aggregate=self._aggregate, gen=self._gen)
+                aggregate=self._aggregate, gen=self._gen, chunk_steps=self._chunk_steps)
         self._hot = (B, device, sess)
         return sess
 
@@ -211,15 +218,7 @@ class Connector:
         return ts._replace(reward=ts.reward.sum(dim=-1), discount=ts.discount.max(dim=-1).values)
 
     # ---------------------------------------------------------------------------------- rollout
-    def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,
-                       want_timestep: bool = False, record: bool = False):
-        """n_steps of `step` under the masked-uniform random policy (ops.random_actions) in ONE
-        kernel launch: the rollout loop of benchmark_on_random_agent.py:59-102 with jumanji's
-        RandomAgent.  Batched states only.  Returns (state, stats, timestep-of-the-last-step or
-        None); stats are per-env int32 counters (include/rbg_prw.h::rbg_rollout_stats).
-        record=True returns (state, actions [n_steps, B, N], TimeStep with a leading time axis)
-        instead: the trajectory the acting loop collects -- entry s is what the s-th
-        `step(state, action)` of the loop returns (what `lax.scan` stacks in run_epoch)."""
+    def _rollout_epochs_for(self, state: State):
         if state.grid.dim() != 3:
             raise ValueError("random_rollout expects a batched state")
         if self._auto_reset and self._gen is None:
@@ -237,18 +236,36 @@ class Connector:
                 epochs = self._rollout_epochs[(B, dev)] = ops.EpochStash(
                     B, self.grid_size, self.num_agents, dev, every=1, serial=True, depth=2,
                     gen=self._gen)
-        if record:
-            so, _, traj = ops.connector_rollout_record(
-                _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
-                self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
-                auto_reset=self._auto_reset, epochs=epochs, gen=self._gen)
-            return _make_state(so, True), traj["action"], _make_timestep(traj, True)
+        return epochs
+
+    def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,
+                       want_timestep: bool = False):
+        """n_steps of `step` under the masked-uniform random policy (ops.random_actions) in ONE
+        kernel launch: the rollout loop of benchmark_on_random_agent.py:59-102 with jumanji's
+        RandomAgent.  Batched states only.  Returns (state, stats, timestep-of-the-last-step or
+        None); stats are per-env int32 counters (include/rbg_prw.h::rbg_rollout_stats)."""
+        epochs = self._rollout_epochs_for(state)
         so, stats, ts = ops.connector_rollout(
             _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
             self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
             auto_reset=self._auto_reset, want_timestep=want_timestep, epochs=epochs,
             gen=self._gen)
         return _make_state(so, True), stats, (_make_timestep(ts, True) if ts is not None else None)
+
+    def random_rollout_record(self, state: State, policy_keys: torch.Tensor, t0: int,
+                              n_steps: int):
+        """The same launch also RECORDING the trajectory the acting loop collects (what `lax.scan`
+        stacks in run_epoch, benchmark_on_random_agent.py:71-86): returns (state, stats, actions
+        [n_steps, B, N], TimeStep with a leading time axis) -- entry s is what the s-th
+        `step(state, action)` of the loop returns."""
+        epochs = self._rollout_epochs_for(state)
+        B, dev = state.grid.shape[0], state.grid.device
+        stats = {k: torch.empty((B,), dtype=torch.int32, device=dev) for k in ops.ROLLOUT_STATS}
+        so, stats, traj = ops.connector_rollout_record(
+            _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,
+            self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
+            auto_reset=self._auto_reset, epochs=epochs, gen=self._gen, stats=stats)
+        return _make_state(so, True), stats, traj["action"], _make_timestep(traj, True)
 
     def _generic_auto_reset(self, so, ts):
         """VmapAutoResetWrapper for a user-defined Python generator (Generator.native_spec() is
@@ -293,8 +310,11 @@ class Connector:
         if agents.id.dim() == grid.dim() - 2:  # a single agent per grid
             N = self.num_agents
             ids = agents.id.reshape(B).long()
-            if bool(((ids < 0) | (ids >= N)).any()):
-                raise ValueError("agent.id outside [0, num_agents)")
+            if not ids.is_cuda:  # (a range check on device ids would cost a host sync per call:
+                if bool(((ids < 0) | (ids >= N)).any()):  # those are clamped instead)
+                    raise ValueError("agent.id outside [0, num_agents)")
+                ids = ids.to(dev)
+            ids = ids.clamp(0, N - 1)
             rows = torch.arange(B, device=dev)
 
             def slot(x, fill):  # (B, 2) -> (B, N, 2) with the agent in its own slot

@@ -70,7 +70,11 @@ class VmapAutoResetWrapper(_Wrapper):
         return self._env.step(state, action)
 
     def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,
-                       want_timestep: bool = False, record: bool = False):
+                       want_timestep: bool = False):
         """n_steps of auto-resetting random-policy stepping in one launch (Connector.random_rollout)."""
-        return self._env.unwrapped.random_rollout(state, policy_keys, t0, n_steps, want_timestep,
-                                                  record)
+        return self._env.unwrapped.random_rollout(state, policy_keys, t0, n_steps, want_timestep)
+
+    def random_rollout_record(self, state: State, policy_keys: torch.Tensor, t0: int,
+                              n_steps: int):
+        """... with every step's TimeStep and action recorded (Connector.random_rollout_record)."""
+        return self._env.unwrapped.random_rollout_record(state, policy_keys, t0, n_steps)

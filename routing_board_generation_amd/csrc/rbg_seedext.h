@@ -194,7 +194,9 @@ __device__ __forceinline__ bool se_can_extend(const uint32_t *board, int P0, uin
 
 // ---------------------------------------------------------------------------------------------
 // The generator.  Lane w < N of the sub-wave owns wire w: (pr, pc) its POSITION cell, (tr, tc) its
-// TARGET cell.  On return the LDS board holds the solved board; returns the number of sweeps.
+// TARGET cell.  On return the LDS board holds the solved board; returns the number of sweeps
+// that changed the board (NOT the reference's step_num, which also counts the idle sweeps a finished
+// board waits through), with the sign bit set if a try loop hit its 512-try cap.
 // `xtra` = se_extra_words() words of LDS private to the board.
 // ---------------------------------------------------------------------------------------------
 template <int LPB>
@@ -263,6 +265,7 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
   const uint32_t cx1 = (l < 2 || l == 4 || l == 5) ? cx0 + 2u : 0u;
 
   int total_sweeps = 0;
+  bool capped = false;  // a try loop ran into its 512-try cap (reported in the sign bit of `sweeps`)
   for (int it = 0; it < p.iterations; ++it) {
     // :189  key, extkey, optkey = split(key, 3): blocks (0,3), (1,4), (2,5)
     Key2 extkey, optkey;
@@ -399,6 +402,7 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
             // (a valid direction comes up with probability >= 1/4 per try; the cap only keeps a
             // corrupted stream from spinning forever: 0.75^512 < 1e-63)
             if (((okm >> idx) & 1u) || pos - s >= 512) {
+              capped = capped || !((okm >> idx) & 1u);
               chosen = ((okm >> idx) & 1u) ? (int)idx : __builtin_ctz(okm);
               need_try = false;
             }
@@ -521,7 +525,8 @@ __device__ __forceinline__ int seed_extension_generate(const SubWave<LPB> &sw, u
       }
     }
   }
-  return total_sweeps;
+  // never observed (0.75^512 < 1e-63): made visible rather than silently picking a direction
+  return sw.ballot(capped) != 0ull ? (int)((uint32_t)total_sweeps | 0x80000000u) : total_sweeps;
 }
 
 }  // namespace rbg

@@ -203,7 +203,7 @@ def test_fused_random_rollout_for_every_generator(rbg, oracle, name, prefetch, r
     t0 = 0
     for launch in range(3):
         if record:
-            state, actions, traj = env.random_rollout(state, akeys, t0, n_steps, record=True)
+            state, stats, actions, traj = env.random_rollout_record(state, akeys, t0, n_steps)
             tnp = {k: v for k, v in timestep_to_np(traj).items()}
         else:
             state, stats, last = env.random_rollout(state, akeys, t0, n_steps, want_timestep=True)
@@ -217,8 +217,8 @@ def test_fused_random_rollout_for_every_generator(rbg, oracle, name, prefetch, r
                 assert_dicts_equal({k: v[s] for k, v in tnp.items()}, ets,
                                    f"{name} launch {launch} step {s} trajectory.")
         assert_dicts_equal(state_to_np(state), est, f"{name} launch {launch} state.")
+        assert (to_np(stats["episodes"]) == episodes).all()  # (the recording launch counts too)
         if not record:
-            assert (to_np(stats["episodes"]) == episodes).all()
             assert_dicts_equal(timestep_to_np(last), ets, f"{name} launch {launch} last timestep.")
         t0 += n_steps
 

@@ -451,7 +451,7 @@ def test_recorded_rollout_matches_oracle_step_by_step(rbg, oracle, m, N, B, step
     state, ts0 = env.reset(keys)
     est, ets = oracle.connector_reset_batch(to_np(keys), m, N, threads=8)
     t0 = 3
-    state, actions, traj = env.unwrapped.random_rollout(state, pkeys, t0, steps, record=True)
+    state, _, actions, traj = env.unwrapped.random_rollout_record(state, pkeys, t0, steps)
     assert actions.shape == (steps, B, N) and traj.observation.grid.shape == (steps, B, N, m, m)
     got = timestep_to_np(traj)
     mask = ets["action_mask"]
@@ -1138,3 +1138,34 @@ def test_grouped_step_loop_equals_one_group(rbg, torch_mod, groups, B):
         for k in a:
             assert torch.equal(a[k], b[k]), k
     assert int(out[0][0]["step_count"].max()) <= 11
+
+
+def test_c4_global_batch_of_baseline_configs_3(rbg, oracle, torch_mod):
+    """BASELINE configs[3]: ParallelRandomWalk 32x32 / 20 agents, batch 32768 sharded over 8 GPUs.
+    On one GPU: the eight shards (sharding.shard_keys, the reference's reshape(devices,
+    per_device, 2), setup_train.py:396-400) generated separately == ONE launch of the whole
+    batch == the oracle, board for board."""
+    from routing_board_generation_amd import ops, sharding
+
+    torch = torch_mod
+    m, N, B, G = 32, 20, 32768, 8
+    keys = _keys(rbg, 0, B)  # split(PRNGKey(0), 32768)
+    whole = ops.prw_generate(keys, m, N, split_first=True, want_solved=True, want_state=True,
+                             want_iters=True)
+    names = ("solved_grid", "train_grid", "start", "target", "position", "step_count", "key_out",
+             "iters")
+    for g in range(G):
+        lo, hi = sharding.shard_bounds(B, g, G)
+        assert hi - lo == 4096
+        part = ops.prw_generate(sharding.shard_keys(keys, g, G), m, N, split_first=True,
+                                want_solved=True, want_state=True, want_iters=True)
+        for k in names:
+            assert torch.equal(part[k], whole[k][lo:hi]), (g, k)
+    est, esolved, eiters = oracle.generate_batch(to_np(keys), m, N, threads=16)
+    assert (to_np(whole["solved_grid"]) == esolved).all()
+    assert (to_np(whole["iters"]) == eiters).all()
+    got = {"grid": to_np(whole["train_grid"]), "start": to_np(whole["start"]),
+           "target": to_np(whole["target"]), "position": to_np(whole["position"]),
+           "key": to_np(whole["key_out"]), "step_count": to_np(whole["step_count"])}
+    assert_dicts_equal(got, est, "C4 global batch: ")
+    check_solved_boards(esolved[:2048], est["start"][:2048], est["target"][:2048])

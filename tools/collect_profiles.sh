@@ -3,17 +3,18 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 P="rocprofv3 --output-format csv"
 run() { # tag-suffix, args...
   sfx=$1; shift
-  timeout -k 10 250 $P --kernel-trace --stats -d gpurun_out/prof_r2${sfx}_trace -o x -- python3 bench.py "$@" > gpurun_out/prof_r2${sfx}_bench.json 2> gpurun_out/prof_r2${sfx}_trace.err
+  timeout -k 10 250 $P --kernel-trace --stats -d gpurun_out/prof_r3${sfx}_trace -o x -- python3 bench.py "$@" > gpurun_out/prof_r3${sfx}_bench.json 2> gpurun_out/prof_r3${sfx}_trace.err
   echo "trace$sfx done"
-  timeout -k 10 250 $P --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_r2${sfx}_fetch -o x -- python3 bench.py "$@" > /dev/null 2> gpurun_out/prof_r2${sfx}_fetch.err
-  timeout -k 10 250 $P --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_r2${sfx}_write -o x -- python3 bench.py "$@" > /dev/null 2> gpurun_out/prof_r2${sfx}_write.err
+  timeout -k 10 250 $P --pmc FETCH_SIZE --kernel-trace -d gpurun_out/prof_r3${sfx}_fetch -o x -- python3 bench.py "$@" > /dev/null 2> gpurun_out/prof_r3${sfx}_fetch.err
+  timeout -k 10 250 $P --pmc WRITE_SIZE --kernel-trace -d gpurun_out/prof_r3${sfx}_write -o x -- python3 bench.py "$@" > /dev/null 2> gpurun_out/prof_r3${sfx}_write.err
   echo "pmc$sfx done"
 }
 run "" --cpu-sample 0
-timeout -k 10 250 $P --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace -d gpurun_out/prof_r2_issue -o x -- python3 bench.py --mode generator --cpu-sample 0 > /dev/null 2> gpurun_out/prof_r2_issue.err
+timeout -k 10 250 $P --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace -d gpurun_out/prof_r3_issue -o x -- python3 bench.py --mode generator --cpu-sample 0 > /dev/null 2> gpurun_out/prof_r3_issue.err
 echo "issue done"
 run _step --mode step-replay
 run _stream --mode stream
+run _stream262k --mode stream --stream-batch 262144
 run _record --mode record
-timeout -k 10 250 $P --kernel-trace --stats -d gpurun_out/prof_r2_configs_trace -o x -- python3 bench.py --all-configs > gpurun_out/prof_r2_configs.json 2> gpurun_out/prof_r2_configs.err
+timeout -k 10 250 $P --kernel-trace --stats -d gpurun_out/prof_r3_configs_trace -o x -- python3 bench.py --all-configs > gpurun_out/prof_r3_configs.json 2> gpurun_out/prof_r3_configs.err
 echo all done
