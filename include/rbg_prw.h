@@ -224,7 +224,7 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  * the envs that restarted recently (a throughput-shaped batch of walks) instead of by every step
  * launch for its own few finished envs (a launch that lasts as long as its longest walk); the
  * step then copies 1.3 KB instead of walking.
- *   depth       slots per env, 1 or 2; slot s of env b is row s * B + b of every array below
+ *   depth       slots per env, 1 .. 4; slot s of env b is row s * B + b of every array below
  *   next        a full rbg_state of depth * B rows: next[r] = reset(split(tag[r])[0])
  *   tag         uint32 [depth*B][2]: the State.key next[r] was generated for (zero-initialised)
  *   ready_at    int32 [depth*B]: first launch tick that may consume the row (zero-initialised)
@@ -232,6 +232,10 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  *   hits        int32 [B], nullable: resets served from the stash (diagnostics; caller zeroes)
  *   misses      int32 [B], nullable: resets of a stash-backed launch that had to run the generator
  *               inline (caller zeroes; a host that sees them grow refills more often)
+ *   scratch     int32 [depth*B + 1], nullable: work area of rbg_stash_refill_gen.  With it the
+ *               refill first lists the rows that need a generator run and then packs them densely
+ *               into wavefronts (SeedExtension runs four boards per wavefront: requests scattered
+ *               over the rows would otherwise leave most of their lanes redoing a neighbour's board)
  * Protocol (host-driven, kernel boundaries only -- no in-kernel cross-stream flags):
  *   every reset/step launch has a tick t = 0, 1, 2, ...  A launch that (re)starts env b with
  *   State.key k writes requests (refill_key, ready_at = t + ready_delay), where the caller
@@ -242,12 +246,17 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  *   stream it takes a stream event.  A row is consumed only if tick >= ready_at[r] and
  *   tag[r] == state.key[b]; otherwise the walk runs inline, so results never depend on timing.
  *   depth 1: the one row of env b is requested for k (the successor of the episode that starts).
- *   depth 2: one row is reserved for k unless one already is, and the other -- the one just
- *   consumed -- is requested for the key of the episode AFTER the next,
- *   split(split(k)[0])[0]: every entry is then asked for a whole episode before it is needed,
- *   which lets a launch of many steps (rbg_connector_rollout) serve all its resets from the
- *   stash, also those of an env that finishes two episodes within it.  The number of walks is
- *   the same as with depth 1; they only happen one episode earlier. */
+ *   depth D > 1: the env wants the successors of its next D episodes, i.e. the rows requested for
+ *   k, f(k), f(f(k)), ... with f(k) = split(split(k)[0])[0] (the wrapper's split, then the
+ *   generator's: the State.key of the episode after the one with State.key k -- known without
+ *   running any generator).  Rows that already carry one of these requests keep it; the others
+ *   (just consumed, or never used) take the missing ones.  Every entry is then asked for D - 1
+ *   whole episodes before it is needed, which lets a launch of many steps
+ *   (rbg_connector_rollout, D = 2) serve all its resets from the stash, also those of an env
+ *   that finishes two episodes within it, and lets a generator whose refill launch is long
+ *   whatever its row count (SequentialRandomWalk, SeedExtension: as long as their slowest board)
+ *   refill rarely.  The number of generator runs is the same as with depth 1; they only happen
+ *   earlier. */
 typedef struct rbg_stash {
   rbg_state next;
   uint32_t *tag;
@@ -255,6 +264,7 @@ typedef struct rbg_stash {
   uint32_t *refill_key;
   int32_t *hits;
   int32_t *misses;
+  int32_t *scratch;
   int32_t depth;
 } rbg_stash;
 

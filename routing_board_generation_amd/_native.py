@@ -53,7 +53,7 @@ class RolloutStats(C.Structure):
 class Stash(C.Structure):
     _fields_ = [("next", State), ("tag", C.c_void_p), ("ready_at", C.c_void_p),
                 ("refill_key", C.c_void_p), ("hits", C.c_void_p), ("misses", C.c_void_p),
-                ("depth", C.c_int32)]
+                ("scratch", C.c_void_p), ("depth", C.c_int32)]
 
 
 class Generator(C.Structure):

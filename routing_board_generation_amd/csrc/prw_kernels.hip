@@ -415,9 +415,10 @@ static int fill_stash(const rbg_stash *stash, StashPtrs *out, const char *who) {
   out->refill_key = stash->refill_key;
   out->hits = stash->hits;
   out->misses = stash->misses;
+  out->scratch = stash->scratch;
   out->depth = stash->depth;
-  if (stash->depth != 1 && stash->depth != 2) {
-    snprintf(g_err, sizeof(g_err), "%s: stash depth must be 1 or 2", who);
+  if (stash->depth < 1 || stash->depth > kMaxStashDepth) {
+    snprintf(g_err, sizeof(g_err), "%s: stash depth must be in [1, %d]", who, kMaxStashDepth);
     return RBG_E_PARAM;
   }
   return 0;
@@ -515,7 +516,11 @@ int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
   if (kind == kGenPrw) {
     lpb = pick_lpb(m, N);
   } else if (kind == kGenSeedExt) {
+#if defined(RBG_SE_REFILL_LPB)  // developer probe (tools/probe_envgen.py --flags)
+    lpb = RBG_SE_REFILL_LPB;
+#else
     lpb = 16;
+#endif
     while (lpb < N) lpb *= 2;
   }
   if (int rc = make_geo(m, N, &a.g, prefix, lpb)) return rc;
@@ -547,6 +552,13 @@ int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
   } else if (kind == kGenDataset) {
     hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenDataset>), grid, block, lds, st, a);
   } else if (kind == kGenSeedExt) {
+    if (a.stash.scratch && lpb < kWaveSize) {
+      // several boards per wavefront: list the requested rows first, then pack them densely
+      if (int rc = check_hip(hipMemsetAsync(a.stash.scratch, 0, sizeof(int32_t), st),
+                             "rbg_stash_refill")) return rc;
+      hipLaunchKernelGGL(stash_list_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
+      a.listed = 1;
+    }
     if (lpb == 16) {
       hipLaunchKernelGGL((stash_refill_gen_kernel<16, kGenSeedExt>), grid, block, lds, st, a);
     } else if (lpb == 32) {

@@ -187,6 +187,7 @@ struct RefillArgs {
   Geo g;
   StashPtrs stash;
   GenSpec gen;
+  int listed;  // the rows to generate are listed in stash.scratch (stash_list_kernel ran)
 };
 
 template <int LPB>
@@ -214,16 +215,41 @@ __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
 // chain phase, one instruction stream for the boards of a wave), so a sub-wave whose row needs
 // nothing does not retire: it redoes the wave's first requested board and stores nothing; a wave
 // none of whose rows is requested retires at once.  blockDim.x / 64 waves per workgroup.
+// Rows with a pending request (tag != refill_key), listed for a dense packing of the producer's
+// wavefronts: scratch[0] = their number (zeroed by the host before), scratch[1..] = the rows, in
+// no particular order (which rows share a wavefront does not matter to any result).
+__global__ void stash_list_kernel(RefillArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  bool need = false;
+  if (r < a.B) {
+    const uint2 want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)r]);
+    const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)r]);
+    need = want.x != have.x || want.y != have.y;
+  }
+  const uint64_t m = __ballot(need);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & (kWaveSize - 1);
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&a.stash.scratch[0], __popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (need) a.stash.scratch[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+}
+
 template <int LPB, int KIND>
 __global__ __launch_bounds__(kBlock) void stash_refill_gen_kernel(RefillArgs a) {
   constexpr int kSubs = SubWave<LPB>::kSubs;
   const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = (int)(blockDim.x >> 6);
-  const int b = (blockIdx.x * wpb + wib) * kSubs + sw.h;
+  const int slot = (blockIdx.x * wpb + wib) * kSubs + sw.h;
   uint2 want = make_uint2(0u, 0u);
   bool need = false;
-  if (b < a.B) {
+  int b = slot;
+  if (a.listed) {  // slot i generates the i-th listed row
+    need = slot < a.stash.scratch[0];
+    b = need ? a.stash.scratch[1 + slot] : 0;
+    if (need) want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
+  } else if (b < a.B) {
     want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
     const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
     need = want.x != have.x || want.y != have.y;

@@ -14,8 +14,10 @@ struct StashPtrs {
   uint32_t *refill_key;  // [depth*B][2] the State.key whose successor the row should hold next
   int32_t *hits;         // [B] nullable diagnostics: resets served from the stash
   int32_t *misses;       // [B] nullable: resets that ran the generator inline although a stash exists
-  int depth;             // 1 or 2
+  int32_t *scratch;      // [depth*B + 1] nullable: [0] = number of listed rows, [1..] = the rows
+  int depth;             // 1 .. kMaxStashDepth
 };
+constexpr int kMaxStashDepth = 4;
 
 // Row of the stash that holds the successor of the episode with State.key `key`, or -1.
 __device__ __forceinline__ int stash_lookup(const StashPtrs &st, int B, int b, Key2 key,
@@ -52,8 +54,8 @@ __device__ __forceinline__ int stash_probe_row(const StashPtrs &st, const StashP
                                                int b, int lane, Key2 key, int tick) {
   const bool ok = st.tag && lane < st.depth && tick >= p.ready_at && p.tag.x == key.a &&
                   p.tag.y == key.b;
-  const uint64_t m = __ballot(ok) & 3ull;  // depth <= 2; the later slot wins, as in stash_lookup
-  return m == 0ull ? -1 : (m & 2ull ? B + b : b);
+  const uint32_t m = (uint32_t)__ballot(ok) & ((1u << kMaxStashDepth) - 1u);
+  return m == 0u ? -1 : (31 - __builtin_clz(m)) * B + b;  // the later slot wins, as in stash_lookup
 }
 
 // An episode that ends on the time limit is known to end as soon as step_count is loaded: its
@@ -105,10 +107,13 @@ __device__ __forceinline__ void stash_row_commit(const SubWave<64> &sw, uint32_t
 }
 
 // After a (re)start with State.key `key`: ask the next refill for what comes after it
-// (include/rbg_prw.h::rbg_stash).  depth 1: the env's one row is requested for `key`.  depth 2:
-// one row is reserved for `key` unless one already is, and the other -- just consumed, or never
-// used -- is requested for the key of the episode after the next, split(split(key)[0])[0]
-// (VmapAutoResetWrapper's split, then the generator's).  Called by the whole sub-wave.
+// (include/rbg_prw.h::rbg_stash).  With `depth` slots per env the env wants the successors of
+// its next `depth` episodes: the rows tagged key, f(key), f(f(key)), ... with
+// f(k) = split(split(k)[0])[0] -- VmapAutoResetWrapper's split, then the generator's, which every
+// generator of rbg_regen.h starts with -- i.e. the State.key of the episode after the one with
+// State.key k; no generator has to run to know it.  Rows that already carry one of those requests
+// keep it (and their ready_at); the others -- just consumed, stale, or never used -- take the
+// missing ones.  depth 1: the one row is requested for `key`.  Called by the whole sub-wave.
 template <int LPB>
 __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const StashPtrs &st, int B,
                                                int b, Key2 key, int ready_at) {
@@ -120,24 +125,45 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
     }
     return;
   }
-  Key2 rk, after, unused;
-  split2_lanes(sw, key, rk, unused);
-  split2_lanes(sw, rk, after, unused);
-  if (sw.l == 0) {
-    const int r0 = b, r1 = B + b;
-    const uint2 k0 = *reinterpret_cast<const uint2 *>(&st.refill_key[2 * (size_t)r0]);
-    const uint2 k1 = *reinterpret_cast<const uint2 *>(&st.refill_key[2 * (size_t)r1]);
-    int other = r1;
-    if (k0.x == key.a && k0.y == key.b) {
-      other = r1;
-    } else if (k1.x == key.a && k1.y == key.b) {
-      other = r0;
-    } else {
-      *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)r0]) = make_uint2(key.a, key.b);
-      st.ready_at[r0] = ready_at;
+  const int D = st.depth < kMaxStashDepth ? st.depth : kMaxStashDepth;
+  Key2 want[kMaxStashDepth];
+  want[0] = key;
+#pragma unroll
+  for (int j = 1; j < kMaxStashDepth; ++j) {
+    want[j] = want[j - 1];
+    if (j < D) {  // (uniform)
+      Key2 rk, unused;
+      split2_lanes(sw, want[j - 1], rk, unused);
+      split2_lanes(sw, rk, want[j], unused);
     }
-    *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)other]) = make_uint2(after.a, after.b);
-    st.ready_at[other] = ready_at;
+  }
+  if (sw.l == 0) {
+    uint2 cur[kMaxStashDepth];
+    uint32_t row_used = 0u, want_met = 0u;
+#pragma unroll
+    for (int s = 0; s < kMaxStashDepth; ++s)
+      cur[s] = s < D ? *reinterpret_cast<const uint2 *>(&st.refill_key[2 * ((size_t)s * B + b)])
+                     : make_uint2(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < kMaxStashDepth; ++j) {
+#pragma unroll
+      for (int s = 0; s < kMaxStashDepth; ++s) {
+        const bool hit = j < D && s < D && !((row_used >> s) & 1u) && !((want_met >> j) & 1u) &&
+                         cur[s].x == want[j].a && cur[s].y == want[j].b;
+        row_used |= (uint32_t)hit << s;
+        want_met |= (uint32_t)hit << j;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxStashDepth; ++j) {
+      if (j < D && !((want_met >> j) & 1u)) {
+        const int s = __builtin_ctz(~row_used);  // a free row exists: D rows, fewer than D kept
+        const size_t r = (size_t)s * B + b;
+        *reinterpret_cast<uint2 *>(&st.refill_key[2 * r]) = make_uint2(want[j].a, want[j].b);
+        st.ready_at[r] = ready_at;
+        row_used |= 1u << s;
+      }
+    }
   }
 }
 

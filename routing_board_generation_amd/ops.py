@@ -510,8 +510,8 @@ def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
 def alloc_stash(B: int, m: int, N: int, device, depth: int = 1) -> dict:
     """Buffers of include/rbg_prw.h::rbg_stash (tag / ready_at / refill_key / hits zeroed);
     `depth` slots per env, slot s of env b in row s * B + b."""
-    if depth not in (1, 2):
-        raise ValueError("stash depth must be 1 or 2")
+    if depth not in (1, 2, 3, 4):
+        raise ValueError("stash depth must be in [1, 4]")
     R = depth * B
     return {"next": alloc_state(R, m, N, device),
             "tag": torch.zeros((R, 2), dtype=torch.uint32, device=device),
@@ -519,6 +519,7 @@ def alloc_stash(B: int, m: int, N: int, device, depth: int = 1) -> dict:
             "refill_key": torch.zeros((R, 2), dtype=torch.uint32, device=device),
             "hits": torch.zeros((B,), dtype=torch.int32, device=device),
             "misses": torch.zeros((B,), dtype=torch.int32, device=device),
+            "scratch": torch.zeros((R + 1,), dtype=torch.int32, device=device),
             "depth": depth}
 
 
@@ -533,8 +534,12 @@ def _stash_struct(stash: dict, B: int, m: int, N: int) -> nat.Stash:
     misses = stash.get("misses")
     if misses is not None:
         _check(misses, torch.int32, (B,), "stash.misses")
+    scratch = stash.get("scratch")
+    if scratch is not None:
+        _check(scratch, torch.int32, (R + 1,), "stash.scratch")
     return nat.Stash(nxt, stash["tag"].data_ptr(), stash["ready_at"].data_ptr(),
-                     stash["refill_key"].data_ptr(), stash["hits"].data_ptr(), _ptr(misses), depth)
+                     stash["refill_key"].data_ptr(), stash["hits"].data_ptr(), _ptr(misses),
+                     _ptr(scratch), depth)
 
 
 def connector_reset_prefetch(keys: torch.Tensor, m: int, N: int, stash: dict, tick: int,

@@ -96,9 +96,10 @@ def aggregate(ets, N):
     return out
 
 
-@pytest.mark.parametrize("prefetch,delay", [(False, 0), (True, 1), (True, 5)])
+@pytest.mark.parametrize("prefetch,delay,depth", [(False, 0, 0), (True, 1, 0), (True, 5, 0),
+                                                  (True, 7, 3), (True, 9, 4)])
 @pytest.mark.parametrize("name", GENERATORS)
-def test_auto_reset_rollout_matches_oracle(rbg, oracle, name, prefetch, delay):
+def test_auto_reset_rollout_matches_oracle(rbg, oracle, name, prefetch, delay, depth):
     """The reference's training env VmapAutoResetWrapper(MultiToSingleWrapper(Connector(g)))
     (setup_train.py:158-167) for every generation_type, several episodes at 16x16/10 under random
     legal actions: state and full timestep after every step."""
@@ -108,6 +109,8 @@ def test_auto_reset_rollout_matches_oracle(rbg, oracle, name, prefetch, delay):
     gen, gen_fn = make_pair(rbg, oracle, name, m, N)
     env = rbg.VmapAutoResetWrapper(rbg.MultiToSingleWrapper(
         rbg.Connector(generator=gen, time_limit=tl)), prefetch=prefetch, prefetch_delay=delay)
+    if depth:  # slots per env of the next-episode stash (default: the generator's own choice)
+        env.unwrapped._gen.refill["depth"] = depth
     keys, akeys = _keys(rbg, 31, B), _keys(rbg, 32, B)
     state, ts = env.reset(keys)
     est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
@@ -131,7 +134,9 @@ def test_auto_reset_rollout_matches_oracle(rbg, oracle, name, prefetch, delay):
             # the generator's own refill producer served the restarts (an entry is usable at most
             # 2 * delay launches after its request; episodes last up to 9 steps)
             hits = int(to_np(sess.epochs.stash["hits"]).sum())
-            assert hits >= (0.8 if delay == 1 else 0.3) * n_last, (hits, n_last)
+            assert sess.epochs.stash["depth"] == (depth or sess.epochs.stash["depth"])
+            # (with 3-4 slots entries are requested 2-3 episodes ahead: nearly every reset hits)
+            assert hits >= (0.8 if delay == 1 or depth else 0.3) * n_last, (hits, n_last)
         sess.drain()
 
 

@@ -23,7 +23,17 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--configs", default="0:1:1,16:1:1,16:1:2,48:1:2,16:0:1,16:0:2,32:0:2,48:0:2",
                     help="K:serial:depth triples; K = 0 is the inline (fused) reset")
+    ap.add_argument("--flags", default="", help="extra hipcc flags: time a variant build of the "
+                                                "library (built here, into gpurun_out/)")
     args = ap.parse_args()
+    if args.flags:
+        from routing_board_generation_amd import _native as nat
+
+        so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                          "librbg_probe_envgen.so")
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        nat.hipcc_compile(args.flags.split() + ["-o", so, nat.SRC_PATH])
+        nat.LIB_PATH = so  # before anything loads the library
     import torch
 
     import routing_board_generation_amd as rbg
