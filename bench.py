@@ -848,7 +848,7 @@ def main() -> None:
                 queue_refill = ep.after_launch
 
                 def after_launch(stream=None):
-                    due = ep.tick % ep.K == ep.K - 1
+                    due = ep.tick == ep._refill_after
                     if due:
                         spans[-1][1].record()  # the run ends before the refill is queued
                     queue_refill(stream)

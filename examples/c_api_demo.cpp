@@ -1,7 +1,8 @@
 // c_api_demo.cpp -- the drop-in boundary without Python or torch: a plain C++ host program that
 // links librbg_prw.so (include/rbg_prw.h) and the HIP runtime, generates the BASELINE configs[1]
 // batch (16x16 grid, 10 agents, 4096 boards from split(PRNGKey(0), 4096)), resets a Connector
-// env on it and runs a 50-step fused random rollout.
+// env on it and runs a 50-step fused random rollout; then steps the same env coupled to another
+// generator (SequentialRandomWalk) through rbg_generator / rbg_step_call / rbg_stash_refill_gen.
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include examples/c_api_demo.cpp \
 //         -L routing_board_generation_amd/lib -lrbg_prw -Wl,-rpath,'$ORIGIN' -o c_api_demo
@@ -93,5 +94,66 @@ int main(int argc, char **argv) {
          (unsigned long long)fnv);
   printf("rollout %d steps: episodes %lld  connections %lld  unconnected_agent_steps %lld  "
          "return %.3f\n", n_steps, eps, conn, pen, 0.1 * (double)conn - 0.03 * (double)pen);
+
+  // The same env hot path for another generator of setup_train.py:112-152 -- online_seq_rw:
+  // VmapAutoResetWrapper(Connector(SequentialRandomWalkGenerator(16, 10))), 20 NOOP steps with a
+  // time limit of 6, next episodes from the generator's own stash (refilled every 4 steps), the
+  // step described by one rbg_step_call.
+  rbg_generator gen = {};
+  gen.kind = RBG_GEN_SEQUENTIAL_RW;
+  const int D = 2;  // stash slots per env
+  rbg_stash stash = {};
+  stash.next = {dalloc<int32_t>((size_t)D * B * m * m), dalloc<int32_t>((size_t)D * B),
+                dalloc<int32_t>((size_t)D * B * N * 2), dalloc<int32_t>((size_t)D * B * N * 2),
+                dalloc<int32_t>((size_t)D * B * N * 2), dalloc<uint32_t>((size_t)D * B * 2)};
+  stash.tag = dalloc<uint32_t>((size_t)D * B * 2);
+  stash.ready_at = dalloc<int32_t>((size_t)D * B);
+  stash.refill_key = dalloc<uint32_t>((size_t)D * B * 2);
+  stash.hits = dalloc<int32_t>(B);
+  stash.misses = dalloc<int32_t>(B);
+  stash.depth = D;
+  HIP_OK(hipMemsetAsync(stash.tag, 0, (size_t)D * B * 8, stream));
+  HIP_OK(hipMemsetAsync(stash.ready_at, 0, (size_t)D * B * 4, stream));
+  HIP_OK(hipMemsetAsync(stash.refill_key, 0, (size_t)D * B * 8, stream));
+  HIP_OK(hipMemsetAsync(stash.hits, 0, (size_t)B * 4, stream));
+  HIP_OK(hipMemsetAsync(stash.misses, 0, (size_t)B * 4, stream));
+  int32_t *action = dalloc<int32_t>((size_t)B * N);
+  HIP_OK(hipMemsetAsync(action, 0, (size_t)B * N * 4, stream));  // NOOP
+  const int K = 4;  // refill period: requests of launches 0..3 are served from launch 4 on
+  int tick = 0;
+  RBG_OK(rbg_connector_reset_gen(&gen, keys, B, m, N, &st, &ts, &stash, tick, K - tick, stream));
+  ++tick;
+  rbg_step_call call = {};
+  call.generator = &gen;
+  call.B = B; call.m = m; call.N = N;
+  call.state_in = call.state_out = st;  // in place
+  call.timestep = ts;
+  call.action = action;
+  call.params = {6, -0.03f, 0.1f, 1};
+  call.stash = &stash;
+  call.stream = stream;
+  for (int s = 0; s < 20; ++s, ++tick) {
+    call.tick = tick;
+    call.ready_delay = K * (tick / K + 1) - tick;
+    RBG_OK(rbg_connector_step_call(&call));
+    if (tick % K == K - 1) RBG_OK(rbg_stash_refill_gen(&gen, B, m, N, &stash, stream));
+  }
+  HIP_OK(hipStreamSynchronize(stream));
+  std::vector<int32_t> h_grid((size_t)B * m * m), h_hits(B), h_miss(B);
+  HIP_OK(hipMemcpy(h_grid.data(), st.grid, h_grid.size() * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_hits.data(), stash.hits, (size_t)B * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_miss.data(), stash.misses, (size_t)B * 4, hipMemcpyDeviceToHost));
+  fnv = 1469598103934665603ull;
+  for (int32_t v : h_grid) {
+    fnv ^= (uint32_t)v;
+    fnv *= 1099511628211ull;
+  }
+  long long hits = 0, misses = 0;
+  for (int b = 0; b < B; ++b) {
+    hits += h_hits[b];
+    misses += h_miss[b];
+  }
+  printf("seq_rw env after 20 steps: grid_fnv1a %016llx  stash hits %lld  misses %lld\n",
+         (unsigned long long)fnv, hits, misses);
   return 0;
 }

@@ -619,7 +619,10 @@ class EpochStash:
         self.K = self.K0 = max(1, int(every))
         self.serial = bool(serial)
         self.tick = 0
-        self._refill_after = self.K - 1  # serial: the launch tick behind which the next refill goes
+        # serial: the launch tick behind which the next refill goes.  The first one follows the very
+        # first launch (the reset): every env's first successor is generated before any episode can
+        # end, instead of the early finishers of the first K steps running the generator inline
+        self._refill_after = 0
         self.stash = alloc_stash(B, m, N, device, depth)
         self.struct = _stash_struct(self.stash, B, m, N)
         self._lib = nat.lib()

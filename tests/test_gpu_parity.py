@@ -697,6 +697,24 @@ def test_c_api_demo_program(oracle, tmp_path):
     assert f"walk_iters_sum {int(iters.sum())} " in out, out
     assert f"solved_fnv1a {fnv:016x}" in out, out
     assert "rollout 50 steps: episodes" in out
+    # the second half of the demo: Connector(SequentialRandomWalkGenerator) under auto-reset, 20
+    # NOOP steps at time_limit 6 -> three restarts per env, served by the generator's own stash
+    st, _, _ = oracle.seq_rw_generator_batch(keys, 16, 10, threads=8)
+    noop = np.zeros((1000, 10), np.int32)
+    for _ in range(20):
+        ts = oracle.connector_step_batch(st, noop, time_limit=6, auto_reset=False, threads=8)
+        idx = np.nonzero(ts["step_type"] == 2)[0]
+        if idx.size:
+            fresh, _, _ = oracle.seq_rw_generator_batch(
+                np.stack([oracle.split(k)[0] for k in st["key"][idx]]), 16, 10, threads=8)
+            for f in st:
+                st[f][idx] = fresh[f]
+    fnv = 1469598103934665603
+    for v in st["grid"].astype(np.uint32).ravel().tolist():
+        fnv = ((fnv ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert f"grid_fnv1a {fnv:016x}" in out, out
+    hits, misses = (int(x) for x in out.split("stash hits ")[1].replace("misses", "").split())
+    assert hits + misses == 3000 and hits >= 2000, out
 
 
 # ------------------------------------------------------------------------------ prefetched resets

@@ -34,7 +34,7 @@ def replay(B, refill_every, auto_reset, skip_refill_spans=True):
             queue_refill = ep.after_launch
 
             def after_launch(stream=None):
-                due = ep.tick % ep.K == ep.K - 1
+                due = ep.tick == ep._refill_after
                 if due:
                     spans[-1][1].record()
                 queue_refill(stream)
