@@ -400,6 +400,8 @@ int rbg_connector_rollout_record(int B, int m, int N, const rbg_state *state_in,
  *   RBG_GEN_SEED_EXTENSION  rl_training/online_generators/random_seed_generator.py:28-57 with
  *                           randomness / two_sided / extension_iterations / max_extension_steps as in
  *                           rbg_seed_extension_generate (the generator's defaults: 0, 1, 1, INT32_MAX)
+ *   RBG_GEN_PARALLEL_RW_PHILOX  nothing in the reference: ParallelRandomWalkPhiloxGenerator, whose
+ *                           State.key is words 0, 1 of philox(key, (0, 0, 0, 3)) instead of a split
  *   RBG_GEN_DATASET         rl_training/offline_generation/dataset_generator_jax.py:112-141:
  *                           sample one of n_boards stored boards, heads / targets int32
  *                           [n_boards][N][2] (agent-major, device memory that outlives the launches) */
@@ -408,6 +410,7 @@ int rbg_connector_rollout_record(int B, int m, int N, const rbg_state *state_in,
 #define RBG_GEN_SEQUENTIAL_RW 2
 #define RBG_GEN_SEED_EXTENSION 3
 #define RBG_GEN_DATASET 4
+#define RBG_GEN_PARALLEL_RW_PHILOX 5 /* the opt-in stream of rbg_prw_generate_philox (not the reference's) */
 
 typedef struct rbg_generator {
   int32_t kind;                 /* RBG_GEN_* */

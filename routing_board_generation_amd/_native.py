@@ -63,7 +63,8 @@ class Generator(C.Structure):
                 ("n_boards", C.c_int32), ("heads", C.c_void_p), ("targets", C.c_void_p)]
 
 
-GEN_PARALLEL_RW, GEN_UNIFORM, GEN_SEQUENTIAL_RW, GEN_SEED_EXTENSION, GEN_DATASET = range(5)
+(GEN_PARALLEL_RW, GEN_UNIFORM, GEN_SEQUENTIAL_RW, GEN_SEED_EXTENSION, GEN_DATASET,
+ GEN_PARALLEL_RW_PHILOX) = range(6)
 
 
 class EnvParams(C.Structure):

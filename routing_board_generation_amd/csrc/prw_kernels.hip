@@ -126,6 +126,8 @@ int fill_gen(const rbg_generator *gen, int m, int N, GenSpec *gs, int *prefix_co
     case RBG_GEN_SEQUENTIAL_RW:
       if (m < 3) return fail(RBG_E_SHAPE, "sequential random walk: m must be >= 3");
       return 0;
+    case RBG_GEN_PARALLEL_RW_PHILOX:
+      return 0;
     case RBG_GEN_SEED_EXTENSION: {
       if (N > (m / 2) * (m / 2))
         return fail(RBG_E_SHAPE, "seed extension: N exceeds the (m/2)^2 seed cells");
@@ -390,6 +392,8 @@ static int launch_env(EnvArgs &a, void *stream, const char *what) {
     launch_env_gen<kGenSeedExt>(a, grid, block, lds, st);
   } else if (a.gen.kind == kGenDataset) {
     launch_env_gen<kGenDataset>(a, grid, block, lds, st);
+  } else if (a.gen.kind == kGenPhilox) {
+    launch_env_gen<kGenPhilox>(a, grid, block, lds, st);
   } else if (a.mode == kModeReset) {
     hipLaunchKernelGGL(connector_reset_kernel, grid, block, lds, st, a);
   } else {
@@ -515,6 +519,11 @@ int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
   int lpb = kWaveSize, wpb = kWavesPerBlock;
   if (kind == kGenPrw) {
     lpb = pick_lpb(m, N);
+  } else if (kind == kGenPhilox) {
+    lpb = N <= 32 ? 32 : kWaveSize;  // lane i = agent i; two boards per wavefront when they fit
+    Geo probe;
+    probe.words = (m + 4) * (m + 4);
+    if (lds_bytes(probe, lpb) > 64u * 1024u) lpb = kWaveSize;
   } else if (kind == kGenSeedExt) {
 #if defined(RBG_SE_REFILL_LPB)  // developer probe (tools/probe_envgen.py --flags)
     lpb = RBG_SE_REFILL_LPB;
@@ -551,6 +560,12 @@ int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
     hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenSeqRw>), grid, block, lds, st, a);
   } else if (kind == kGenDataset) {
     hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenDataset>), grid, block, lds, st, a);
+  } else if (kind == kGenPhilox) {
+    if (lpb == 32) {
+      hipLaunchKernelGGL((stash_refill_gen_kernel<32, kGenPhilox>), grid, block, lds, st, a);
+    } else {
+      hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenPhilox>), grid, block, lds, st, a);
+    }
   } else if (kind == kGenSeedExt) {
     if (a.stash.scratch && lpb < kWaveSize) {
       // several boards per wavefront: list the requested rows first, then pack them densely
@@ -702,6 +717,7 @@ int rbg_connector_rollout_gen(const rbg_generator *generator, int B, int m, int 
     if (kind == kGenUniform) launch_rollout_gen<kGenUniform>(a, record, grid, lds, st);
     else if (kind == kGenSeqRw) launch_rollout_gen<kGenSeqRw>(a, record, grid, lds, st);
     else if (kind == kGenSeedExt) launch_rollout_gen<kGenSeedExt>(a, record, grid, lds, st);
+    else if (kind == kGenPhilox) launch_rollout_gen<kGenPhilox>(a, record, grid, lds, st);
     else launch_rollout_gen<kGenDataset>(a, record, grid, lds, st);
     return check_hip(hipGetLastError(), "rbg_connector_rollout");
   }

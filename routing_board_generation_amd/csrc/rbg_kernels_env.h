@@ -56,7 +56,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
     kin.b = a.keys[2 * (size_t)b + 1];
     const Key2 key = regenerate_kind<64, KIND>(sw, board, W, g, N, kin, ag, a.gen);
     store_state(sw, board, g, N, b, ag, 0, key, a.out);
-    request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+    request_refill<KIND>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
     write_observation(sw, board, g, N, b, ag, 0, a.ts,
                       lane < N ? action_mask_bits(board, g, ag, lane) : 1u);
     write_extras(sw, board, g, N, b, ag, a.ts);
@@ -140,7 +140,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
       key = regenerate_kind<64, KIND>(sw, board, W, g, N, rk, ag, a.gen);
     }
     step_count = 0;
-    request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+    request_refill<KIND>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
     const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
     store_state(sw, board, g, N, b, ag, step_count, key, a.out);
     write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);

@@ -141,7 +141,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a) {
         }
         step_count = 0;
         key = uni<LPB>(key);
-        request_refill(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+        request_refill<KIND>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
         bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
       }
     }

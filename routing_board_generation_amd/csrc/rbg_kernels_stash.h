@@ -2,6 +2,7 @@
 // lookup, early probes, row prefetch, refill requests.  Shared by the env kernels and the rollout.
 #pragma once
 #include "rbg_kernels_common.h"
+#include "rbg_regen.h"
 
 namespace {
 
@@ -109,12 +110,12 @@ __device__ __forceinline__ void stash_row_commit(const SubWave<64> &sw, uint32_t
 // After a (re)start with State.key `key`: ask the next refill for what comes after it
 // (include/rbg_prw.h::rbg_stash).  With `depth` slots per env the env wants the successors of
 // its next `depth` episodes: the rows tagged key, f(key), f(f(key)), ... with
-// f(k) = split(split(k)[0])[0] -- VmapAutoResetWrapper's split, then the generator's, which every
-// generator of rbg_regen.h starts with -- i.e. the State.key of the episode after the one with
-// State.key k; no generator has to run to know it.  Rows that already carry one of those requests
+// f = rbg_regen.h::next_state_key<KIND> -- split(split(k)[0])[0] for the reference's generators:
+// VmapAutoResetWrapper's split, then the generator's -- i.e. the State.key of the episode after
+// the one with State.key k; no generator has to run to know it.  Rows that already carry one of those requests
 // keep it (and their ready_at); the others -- just consumed, stale, or never used -- take the
 // missing ones.  depth 1: the one row is requested for `key`.  Called by the whole sub-wave.
-template <int LPB>
+template <int KIND, int LPB>
 __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const StashPtrs &st, int B,
                                                int b, Key2 key, int ready_at) {
   if (!st.refill_key) return;
@@ -131,11 +132,7 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
 #pragma unroll
   for (int j = 1; j < kMaxStashDepth; ++j) {
     want[j] = want[j - 1];
-    if (j < D) {  // (uniform)
-      Key2 rk, unused;
-      split2_lanes(sw, want[j - 1], rk, unused);
-      split2_lanes(sw, rk, want[j], unused);
-    }
+    if (j < D) want[j] = next_state_key<LPB, KIND>(sw, want[j - 1]);  // (uniform branch)
   }
   if (sw.l == 0) {
     uint2 cur[kMaxStashDepth];

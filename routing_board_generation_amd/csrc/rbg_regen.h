@@ -2,7 +2,7 @@
 // reference can put behind Connector (routing_board_generation/rl_training/setup_train.py:112-152):
 // what the env kernels run when an episode (re)starts and what the stash refill runs ahead of time.
 //
-// All of them share one key protocol -- `key, _ = split(key)` first, State.key = that child
+// All of the reference's share one key protocol -- `key, _ = split(key)` first, State.key = that child
 // (parallel_random_walk_generator.py:52, uniform_generator.py:76, sequential_random_walk_generator.py
 // :40, random_seed_generator.py:34, offline_generation/dataset_generator_jax.py:114) -- which is
 // what lets the next-episode stash name the episode after the next without generating anything
@@ -11,11 +11,32 @@
 #include "rbg_env.h"
 #include "rbg_seedext.h"
 #include "rbg_seqwalk.h"
+#include "rbg_walk_philox.h"
 
 namespace rbg {
 
 // include/rbg_prw.h::RBG_GEN_*
-enum { kGenPrw = 0, kGenUniform = 1, kGenSeqRw = 2, kGenSeedExt = 3, kGenDataset = 4 };
+enum { kGenPrw = 0, kGenUniform = 1, kGenSeqRw = 2, kGenSeedExt = 3, kGenDataset = 4,
+       kGenPhilox = 5 };
+
+// State.key of the episode AFTER the one whose State.key is k: VmapAutoResetWrapper resets from
+// split(k)[0], and the generator derives its State.key from that -- for the reference's generators
+// by another split (see above), for the opt-in Philox walk as words 0, 1 of
+// philox(key, (0, 0, 0, 3)) (include/rbg_prw.h).  No generator has to run to know it, which is
+// what lets a stash request rows several episodes ahead (rbg_kernels_stash.h::request_refill).
+template <int LPB, int KIND>
+__device__ __forceinline__ Key2 next_state_key(const SubWave<LPB> &sw, Key2 k) {
+  Key2 rk, unused, out;
+  split2_lanes(sw, k, rk, unused);
+  if constexpr (KIND == kGenPhilox) {
+    const Philox4 p = philox4x32_10(rk.a, rk.b, 0u, 0u, 0u, 3u);
+    out.a = p.w[0];
+    out.b = p.w[1];
+  } else {
+    split2_lanes(sw, rk, out, unused);
+  }
+  return out;
+}
 
 struct GenSpec {
   int kind;
@@ -96,6 +117,19 @@ __device__ __forceinline__ Key2 regenerate_kind(const SubWave<LPB> &sw, uint32_t
     ag.tr = tr;
     ag.tc = tc;
     return key;
+  } else if constexpr (KIND == kGenPhilox) {
+    // ParallelRandomWalkGenerator(stream = "philox") (rbg_walk_philox.h; project-defined stream):
+    // the key is used as it comes, State.key = words 0, 1 of philox(key, (0, 0, 0, 3))
+    Walker w;
+    prw_walk_philox(sw, board, W, g, N, key_in, w);
+    board_to_training(sw, board, g);
+    ag.r0 = ag.r = w.r0;
+    ag.c0 = ag.c = w.c0;
+    ag.tr = w.r;
+    ag.tc = w.c;
+    const Philox4 p = philox4x32_10(key_in.a, key_in.b, 0u, 0u, 0u, 3u);
+    Key2 out = {p.w[0], p.w[1]};
+    return out;
   } else {
     static_assert(KIND == kGenDataset, "unknown generator kind");
     // BoardDatasetGeneratorJAX.__call__ (dataset_generator_jax.py:112-141): key, _ = split(key);

@@ -39,7 +39,8 @@ class ParallelRandomWalkPhiloxGenerator(Generator):
     defined by this project: boards are valid, solvable and deterministic per key, but they are
     NOT the reference's boards for that key -- the default `ParallelRandomWalkGenerator` is the
     bit-exact one.  The stream is specified in include/rbg_prw.h.  A `Connector` built on it
-    resets through generator(key) + `rbg_connector_observe` (no fused auto-reset)."""
+    gets the same fused reset / next-episode stash / fused rollouts as the other generators
+    (RBG_GEN_PARALLEL_RW_PHILOX)."""
 
     def __call__(self, key: torch.Tensor) -> State:
         batched = key.dim() == 2
@@ -49,3 +50,8 @@ class ParallelRandomWalkPhiloxGenerator(Generator):
               "position": out["position"], "key": out["key_out"],
               "step_count": out["step_count"]}
         return state_from_bufs(st, batched)
+
+    def native_spec(self):
+        from .. import _native as nat
+
+        return ops.GeneratorSpec(nat.GEN_PARALLEL_RW_PHILOX)

@@ -36,13 +36,20 @@ def _keys(rbg, seed, B):
 
 
 GENERATORS = ["online_parallel_rw", "online_uniform", "online_seq_rw", "online_random_seed",
-              "offline_parallel_rw", "offline_seed_extension"]
+              "offline_parallel_rw", "offline_seed_extension",
+              # not a generation_type of the reference: the opt-in Philox stream of the walk, whose
+              # State.key is not a split (its own rule in the stash protocol); checked against
+              # this project's restatement of the stream only (oracle/prw_philox.c)
+              "parallel_rw_philox"]
 
 
 def make_pair(rbg, oracle, name, m, N, n_boards=64):
     """(package generator, oracle batch function keys [B, 2] -> state dict)."""
     from routing_board_generation_amd.interface.board_generator_interface import make_online_generator
 
+    if name == "parallel_rw_philox":
+        return (rbg.ParallelRandomWalkPhiloxGenerator(m, N),
+                lambda keys: oracle.prw_philox_batch(keys, m, N, threads=8)[0])
     if name.startswith("offline"):
         # cfg.env.seed_extension.* of agent_training/configs/env/connector.yaml go to the dataset
         gen = make_online_generator(name, m, N, randomness=0.0, two_sided=True,
@@ -149,8 +156,9 @@ def test_native_generators_take_the_fused_path(rbg, name):
     from routing_board_generation_amd.interface.board_generator_interface import make_online_generator
 
     kw = dict(randomness=0.0, two_sided=True, number_of_boards=16) if name.startswith("offline") else {}
-    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=make_online_generator(name, 8, 3, **kw),
-                                                 time_limit=2))
+    gen = (rbg.ParallelRandomWalkPhiloxGenerator(8, 3) if name == "parallel_rw_philox"
+           else make_online_generator(name, 8, 3, **kw))
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=2))
 
     def refuse(*a, **k):
         raise AssertionError("generic auto-reset path taken")
