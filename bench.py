@@ -317,8 +317,16 @@ def cpu_baseline(sample_batches: int):
 def timed(fn, reps):
     import torch
 
-    for _ in range(3):
+    # warm up for ~30 ms of GPU work (at least 3 calls): a row that follows a host-only stretch or
+    # a tiny configuration otherwise times the clock ramp and first-use costs of its kernel (the
+    # C2 row after the one-board C1 row read 83 instead of 32 us per launch)
+    t_end = time.perf_counter() + 0.03
+    calls = 0
+    while calls < 3 or (time.perf_counter() < t_end and calls < 2000):
         fn()
+        calls += 1
+        if calls % 16 == 0:
+            torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
