@@ -174,10 +174,11 @@ void launch_env_gen(const EnvArgs &a, dim3 grid, dim3 block, size_t lds, hipStre
 template <int KIND>
 void launch_rollout_gen(const RolloutArgs &a, bool record, dim3 grid, size_t lds,
                                hipStream_t st) {
+  const dim3 block(a.block_threads);
   if (record) {
-    hipLaunchKernelGGL((connector_rollout_gen_kernel<KIND, true>), grid, dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((connector_rollout_gen_kernel<KIND, true>), grid, block, lds, st, a);
   } else {
-    hipLaunchKernelGGL((connector_rollout_gen_kernel<KIND, false>), grid, dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((connector_rollout_gen_kernel<KIND, false>), grid, block, lds, st, a);
   }
 }
 
@@ -377,10 +378,14 @@ int rbg_uniform_generate(const uint32_t *keys, int B, int m, int N, int32_t *tra
 }
 
 static int launch_env(EnvArgs &a, void *stream, const char *what) {
-  const dim3 grid((a.B + kEnvWavesPerBlock - 1) / kEnvWavesPerBlock),
-      block(kWaveSize * kEnvWavesPerBlock);
-  const size_t lds = lds_bytes(a.g) / kWavesPerBlock * kEnvWavesPerBlock +
-                     (size_t)kEnvWavesPerBlock * (size_t)a.gen.extra_words * sizeof(uint32_t);
+  // waves (envs) per workgroup: 4, fewer when a generator's own LDS area (SeedExtension at large
+  // grids) would push the workgroup beyond 64 KiB
+  const size_t per_env = lds_bytes(a.g) / kWavesPerBlock + (size_t)a.gen.extra_words * sizeof(uint32_t);
+  int wpb = kEnvWavesPerBlock;
+  while (wpb > 1 && a.gen.kind != kGenPrw && (size_t)wpb * per_env > 64u * 1024u) wpb /= 2;
+  if ((size_t)wpb * per_env > 64u * 1024u) return fail(RBG_E_SHAPE, "env launch: board too large");
+  const dim3 grid((a.B + wpb - 1) / wpb), block(kWaveSize * wpb);
+  const size_t lds = (size_t)wpb * per_env;
   hipStream_t st = (hipStream_t)stream;
   if (a.mode == kModeObserve) {
     hipLaunchKernelGGL(connector_observe_kernel, grid, block, lds, st, a);
@@ -708,12 +713,18 @@ int rbg_connector_rollout_gen(const rbg_generator *generator, int B, int m, int 
     e.policy_keys = policy_keys; e.policy_t = t0; e.gen = a.gen;
     return launch_env(e, stream, "rbg_connector_rollout");
   }
-  const int envs_per_block = kWavesPerBlock * (kWaveSize / lpb);
+  int envs_per_block = kWavesPerBlock * (kWaveSize / lpb);
+  size_t lds = lds_bytes(a.g, lpb) + (size_t)envs_per_block * (size_t)a.gen.extra_words *
+                                         sizeof(uint32_t);
+  while (kind != kGenPrw && envs_per_block > 1 && lds > 64u * 1024u) {
+    envs_per_block /= 2;  // (one env per wave for these kinds: fewer waves per workgroup)
+    lds /= 2;
+  }
+  if (lds > 64u * 1024u) return fail(RBG_E_SHAPE, "rbg_connector_rollout: board too large");
   const dim3 grid((B + envs_per_block - 1) / envs_per_block), block(kBlock);
-  const size_t lds = lds_bytes(a.g, lpb) + (size_t)envs_per_block * (size_t)a.gen.extra_words *
-                                               sizeof(uint32_t);
   hipStream_t st = (hipStream_t)stream;
   if (kind != kGenPrw) {
+    a.block_threads = kWaveSize * envs_per_block;
     if (kind == kGenUniform) launch_rollout_gen<kGenUniform>(a, record, grid, lds, st);
     else if (kind == kGenSeqRw) launch_rollout_gen<kGenSeqRw>(a, record, grid, lds, st);
     else if (kind == kGenSeedExt) launch_rollout_gen<kGenSeedExt>(a, record, grid, lds, st);

@@ -42,7 +42,10 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
   const int lane = threadIdx.x & (kWaveSize - 1);
   const SubWave<64> sw(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.x * kEnvWavesPerBlock + wib;
+  // (the other generators' kernels may run fewer waves per workgroup: SeedExtension's LDS area
+  // at large grids -- launch_env)
+  const int wpb = KIND == kGenPrw ? kEnvWavesPerBlock : (int)(blockDim.x >> 6);
+  const int b = blockIdx.x * wpb + wib;
   if (b >= a.B) return;
   uint32_t *board = g_lds + wib * env_slab_words<64>(a.g, a.gen);
   uint32_t *W = board + board_words(a.g);

@@ -35,6 +35,7 @@ struct RolloutArgs {
   TimestepPtrs traj;     // kRecord: every step's timestep, arrays [n_steps][B]... (members nullable)
   int32_t *traj_action;  // kRecord: the actions taken, [n_steps][B][N] (nullable)
   GenSpec gen;           // the env's generator (rbg_regen.h); all zero = ParallelRandomWalk
+  int block_threads;     // host side only: workgroup size of the launch (other generators' kernels)
 };
 
 // One env per sub-wave of LPB lanes (the host picks the smallest LPB that holds the walk's 2N + 2
@@ -74,7 +75,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a) {
   const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
   const int l = sw.l;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = (blockIdx.x * kWavesPerBlock + wib) * kSubs + sw.h;
+  const int wpb = KIND == kGenPrw ? kWavesPerBlock : (int)(blockDim.x >> 6);
+  const int b = (blockIdx.x * wpb + wib) * kSubs + sw.h;
   if (b >= a.B) return;  // per sub-wave: the rest of the wave carries on
   const Geo g = a.g;
   uint32_t *board = g_lds + (wib * kSubs + sw.h) * env_slab_words<LPB>(g, a.gen);

@@ -265,3 +265,43 @@ def test_adaptive_refill_period_follows_short_episodes(rbg, oracle):
     hits = int(to_np(sess.epochs.stash["hits"]).sum())
     assert misses > 0 and hits > misses, (hits, misses)
     sess.drain()
+
+
+SHAPES = [(5, 2, 9), (7, 4, 33), (12, 33, 16), (32, 20, 12), (40, 15, 8)]
+
+
+@pytest.mark.parametrize("m,N,B", SHAPES)
+@pytest.mark.parametrize("name", GENERATORS)
+def test_env_generators_at_other_shapes(rbg, oracle, name, m, N, B):
+    """Odd and large grids, many agents (N = 33: full-wave boards everywhere; 40x40 SeedExtension:
+    its LDS area forces fewer waves per workgroup in the env kernels): reset, auto-resetting steps
+    with and without the stash, one recording rollout launch -- all against the oracle."""
+    from routing_board_generation_amd import ops
+
+    tl = 4
+    gen, gen_fn = make_pair(rbg, oracle, name, m, N, n_boards=24)
+    keys, akeys = _keys(rbg, 81, B), _keys(rbg, 82, B)
+    for prefetch in (False, True):
+        env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl),
+                                       prefetch=prefetch, prefetch_delay=2)
+        state, ts = env.reset(keys)
+        est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
+        assert_dicts_equal(state_to_np(state), est, f"{name} {m}x{m}/{N} reset state.")
+        for t in range(11):
+            action = ops.random_actions(akeys, t, ts.observation.action_mask)
+            eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+            state, ts = env.step(state, action)
+            ets = oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl)
+            assert_dicts_equal(state_to_np(state), est, f"{name} {m}x{m}/{N} step {t} state.")
+            assert_dicts_equal(timestep_to_np(ts), ets, f"{name} {m}x{m}/{N} step {t} timestep.")
+        state, stats, actions, traj = env.random_rollout_record(state, akeys, 11, 6)
+        tnp = timestep_to_np(traj)
+        for s in range(6):
+            eaction = oracle.random_actions_batch(to_np(akeys), 11 + s, ets["action_mask"])
+            ets = oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl)
+            assert (to_np(actions[s]) == eaction).all()
+            assert_dicts_equal({k: v[s] for k, v in tnp.items()}, ets,
+                               f"{name} {m}x{m}/{N} rollout step {s}.")
+        assert_dicts_equal(state_to_np(state), est, f"{name} {m}x{m}/{N} rollout state.")
+        for sess in env.unwrapped._sessions.values():
+            sess.drain()
