@@ -218,7 +218,7 @@ class Connector:
         return ts._replace(reward=ts.reward.sum(dim=-1), discount=ts.discount.max(dim=-1).values)
 
     # ---------------------------------------------------------------------------------- rollout
-    def _rollout_epochs_for(self, state: State):
+    def _rollout_epochs_for(self, state: State, record: bool = False):
         if state.grid.dim() != 3:
             raise ValueError("random_rollout expects a batched state")
         if self._auto_reset and self._gen is None:
@@ -226,7 +226,11 @@ class Connector:
                 "fused rollouts need a generator the launch can run itself (Generator.native_spec); "
                 "a user-defined Python generator steps through Connector.step")
         epochs = None
-        if self._auto_reset and self._prefetch_delay != 0:
+        # (measured per generator, tools/probe_rollout_gen.py: a stash pays in a many-step launch
+        # only where running the generator inline stalls it -- GeneratorSpec.refill)
+        want = self._gen is not None and self._gen.refill.get(
+            "record_stash" if record else "rollout_stash", not record)
+        if self._auto_reset and self._prefetch_delay != 0 and want:
             # two-slot next-episode stash, refilled after every launch: also an env that finishes
             # two episodes within the launch finds both successors ready
             B, dev = state.grid.shape[0], state.grid.device
@@ -258,7 +262,7 @@ class Connector:
         stacks in run_epoch, benchmark_on_random_agent.py:71-86): returns (state, stats, actions
         [n_steps, B, N], TimeStep with a leading time axis) -- entry s is what the s-th
         `step(state, action)` of the loop returns."""
-        epochs = self._rollout_epochs_for(state)
+        epochs = self._rollout_epochs_for(state, record=True)
         B, dev = state.grid.shape[0], state.grid.device
         stats = {k: torch.empty((B,), dtype=torch.int32, device=dev) for k in ops.ROLLOUT_STATS}
         so, stats, traj = ops.connector_rollout_record(

@@ -77,7 +77,7 @@ class BoardDatasetGeneratorJAX(Generator):
 
         # sampling a stored board is cheaper than a stash row copy: no stash
         return ops.GeneratorSpec(nat.GEN_DATASET, heads=self._heads, targets=self._targets,
-                                 refill={"every": 0})
+                                 refill={"every": 0, "rollout_stash": False})
 
     def print_board(self, which_board: int) -> torch.Tensor:
         """:143-155 -- the training grid of board `which_board`."""

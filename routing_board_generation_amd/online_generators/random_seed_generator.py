@@ -33,7 +33,7 @@ class SeedExtensionGenerator(Generator):
         # (refill: as for SequentialRandomWalk -- a launch of ~1.4 ms whatever its row count)
         return ops.GeneratorSpec(nat.GEN_SEED_EXTENSION, randomness=0.0, two_sided=True,
                                  extension_iterations=1, max_extension_steps=ops.INT32_MAX,
-                                 refill={"every": 48, "depth": 2, "adaptive": True})
+                                 refill={"every": 48, "depth": 2, "adaptive": True, "record_stash": True})
 
 
 RandomSeedGenerator = SeedExtensionGenerator

@@ -29,4 +29,4 @@ class SequentialRandomWalkGenerator(Generator):
 
         # a refill launch lasts as long as its slowest board (~0.4 ms at 16x16/10) however few rows
         # it generates: few, large refills, every entry requested two episodes ahead
-        return ops.GeneratorSpec(nat.GEN_SEQUENTIAL_RW, refill={"every": 48, "depth": 2, "adaptive": True})
+        return ops.GeneratorSpec(nat.GEN_SEQUENTIAL_RW, refill={"every": 48, "depth": 2, "adaptive": True, "rollout_stash": False})

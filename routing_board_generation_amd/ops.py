@@ -53,8 +53,10 @@ INT32_MAX = 2 ** 31 - 1
 class GeneratorSpec:
     """Host side of include/rbg_prw.h::rbg_generator: which generator (re)starts episodes inside
     the env launches (setup_train.py:112-152), with the tensors it points to kept alive.
-    `refill` = how its next-episode stash is best refilled (EpochStash arguments; measured,
-    DESIGN.md 4.2)."""
+    `refill` = how its next-episode stash is best used (measured): "every",
+    "depth", "serial", "adaptive" for the per-step path (EpochStash arguments; every = 0: no
+    stash), "rollout_stash" / "record_stash": whether the fused / the recording rollout launch
+    takes its resets from a stash (defaults True / False)."""
 
     def __init__(self, kind: int, randomness: float = 0.0, two_sided: bool = True,
                  extension_iterations: int = 1, max_extension_steps: int = INT32_MAX,
@@ -1049,8 +1051,8 @@ class ConnectorSession:
         if self.K:
             if self.epochs is not None:
                 self.epochs.drain()
-            kw = dict(self.gen.refill) if self.gen is not None else {}
-            kw.pop("every", None)
+            kw = ({k: v for k, v in self.gen.refill.items() if k in ("depth", "serial", "adaptive")}
+                  if self.gen is not None else {})
             ep = self.epochs = EpochStash(self.B, self.m, self.N, self.device, self.K,
                                           gen=self.gen, **kw)
             self._call.stash = C.pointer(ep.struct)

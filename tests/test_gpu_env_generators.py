@@ -210,6 +210,8 @@ def test_fused_random_rollout_for_every_generator(rbg, oracle, name, prefetch, r
     gen, gen_fn = make_pair(rbg, oracle, name, m, N)
     env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl),
                                    prefetch=prefetch, prefetch_delay=1)
+    if prefetch:  # the stash path for every generator, whatever its measured preference
+        env.unwrapped._gen.refill.update(rollout_stash=True, record_stash=True)
     keys, akeys = _keys(rbg, 41, B), _keys(rbg, 42, B)
     state, ts = env.reset(keys)
     est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
@@ -284,6 +286,8 @@ def test_env_generators_at_other_shapes(rbg, oracle, name, m, N, B):
     for prefetch in (False, True):
         env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl),
                                        prefetch=prefetch, prefetch_delay=2)
+        if prefetch:
+            env.unwrapped._gen.refill.update(rollout_stash=True, record_stash=True)
         state, ts = env.reset(keys)
         est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
         assert_dicts_equal(state_to_np(state), est, f"{name} {m}x{m}/{N} reset state.")
