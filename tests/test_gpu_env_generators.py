@@ -309,3 +309,69 @@ def test_env_generators_at_other_shapes(rbg, oracle, name, m, N, B):
         assert_dicts_equal(state_to_np(state), est, f"{name} {m}x{m}/{N} rollout state.")
         for sess in env.unwrapped._sessions.values():
             sess.drain()
+
+
+@pytest.mark.parametrize("name", ["online_random_seed", "online_uniform"])
+def test_donated_stepping_for_other_generators(rbg, oracle, name):
+    """Connector(donate=True) -- the State advanced in place, two alternating TimeStep buffer
+    sets -- with a generator other than the walk behind it."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, tl = 16, 10, 80, 6
+    gen, gen_fn = make_pair(rbg, oracle, name, m, N)
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl, donate=True),
+                                   prefetch=True, prefetch_delay=3)
+    keys, akeys = _keys(rbg, 91, B), _keys(rbg, 92, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
+    grid_ptr = state.grid.data_ptr()
+    for t in range(25):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        state, ts = env.step(state, action)
+        ets = oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl)
+        assert state.grid.data_ptr() == grid_ptr  # in place
+        assert_dicts_equal(state_to_np(state), est, f"{name} step {t} state.")
+        assert_dicts_equal(timestep_to_np(ts), ets, f"{name} step {t} timestep.")
+    for sess in env.unwrapped._sessions.values():
+        sess.drain()
+
+
+def test_step_and_refill_of_another_generator_capture_into_a_graph(rbg, oracle):
+    """The generator-agnostic calls keep the C-ABI's contract -- asynchronous on the caller's
+    stream, no hidden allocation or synchronisation -- so a step (with the SeedExtension generator
+    behind it) and its stash refill (a memset, the row-listing launch and the producer) capture
+    into a hipGraph and replay."""
+    import torch
+
+    from routing_board_generation_amd import ops
+
+    m, N, B, tl = 12, 6, 48, 3
+    gen, gen_fn = make_pair(rbg, oracle, "online_random_seed", m, N)
+    spec = gen.native_spec()
+    keys = _keys(rbg, 95, B)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        st, ts = ops.alloc_state(B, m, N, keys.device), ops.alloc_timestep(B, m, N, keys.device)
+        stash = ops.alloc_stash(B, m, N, keys.device, depth=2)
+        ops.connector_reset_prefetch(keys, m, N, stash, 0, 1, state=st, timestep=ts, gen=spec)
+        ops.stash_refill(stash, m, gen=spec)
+        noop = torch.zeros((B, N), dtype=torch.int32, device=keys.device)
+        # every launch of the graph is "tick 1 + refill": entries requested in it are usable in
+        # the next replay (ready_delay 0 would be wrong: the refill follows the step)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ops.connector_step_prefetch(st, noop, stash, 1, 0, time_limit=tl, state_out=st,
+                                        timestep=ts, gen=spec)
+            ops.stash_refill(stash, m, gen=spec)
+    torch.cuda.current_stream().wait_stream(side)
+    est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
+    for t in range(10):
+        graph.replay()
+        torch.cuda.synchronize()
+        ets = oracle_auto_reset_step(oracle, gen_fn, est, to_np(noop), tl)
+        got = {k: to_np(v) for k, v in st.items()}
+        assert_dicts_equal(got, est, f"replay {t} state.")
+        assert (to_np(ts["obs_grid"]) == ets["obs_grid"]).all()
+    assert int(to_np(stash["hits"]).sum()) >= 2 * B  # three restarts per env, all but maybe the first from the stash
