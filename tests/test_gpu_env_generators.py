@@ -375,3 +375,23 @@ def test_step_and_refill_of_another_generator_capture_into_a_graph(rbg, oracle):
         assert_dicts_equal(got, est, f"replay {t} state.")
         assert (to_np(ts["obs_grid"]) == ets["obs_grid"]).all()
     assert int(to_np(stash["hits"]).sum()) >= 2 * B  # three restarts per env, all but maybe the first from the stash
+
+
+def test_benchmark_on_random_agent_example_runs():
+    """examples/benchmark_on_random_agent.py: the reference's generator comparison under a random
+    agent (BenchmarkData's fields per epoch) from the fused rollout's counters."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output(
+        [sys.executable, os.path.join(root, "examples", "benchmark_on_random_agent.py"),
+         "--epochs", "2", "--batch", "256", "--n-steps", "60"], text=True, cwd=root, timeout=600)
+    rows = [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+    assert [r["generator_type"] for r in rows] == GENERATORS[:6]
+    for r in rows:
+        assert len(r["episode_length"]) == 2 and 1.0 <= r["average_steps_till_board_terminates"] <= 50.0
+        assert 0.0 <= r["average_proportion_of_wires_connected"] <= 1.0
+        assert r["average_total_wire_length"] >= 0.0 and r["average_reward_per_wire"] < 0.5
