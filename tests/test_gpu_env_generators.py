@@ -395,3 +395,34 @@ def test_benchmark_on_random_agent_example_runs():
         assert len(r["episode_length"]) == 2 and 1.0 <= r["average_steps_till_board_terminates"] <= 50.0
         assert 0.0 <= r["average_proportion_of_wires_connected"] <= 1.0
         assert r["average_total_wire_length"] >= 0.0 and r["average_reward_per_wire"] < 0.5
+
+
+@pytest.mark.parametrize("depth,delay,tl", [(2, 2, 3), (3, 5, 3), (4, 11, 2), (4, 3, 5), (2, 13, 4)])
+def test_stash_request_rule_under_hits_and_misses(rbg, oracle, depth, delay, tl):
+    """Short episodes against long refill periods: resets are a mix of stash hits (from any of
+    the 2-4 slots) and misses that run the generator inline, rows go stale and are re-requested
+    -- the results must be the oracle's whatever the mix."""
+    from routing_board_generation_amd import ops
+
+    m, N, B, steps = 8, 4, 200, 90
+    gen, gen_fn = make_pair(rbg, oracle, "online_uniform", m, N)
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl),
+                                   prefetch=True, prefetch_delay=delay)
+    env.unwrapped._gen.refill["depth"] = depth
+    keys, akeys = _keys(rbg, 55, B), _keys(rbg, 56, B)
+    state, ts = env.reset(keys)
+    est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
+    for t in range(steps):
+        action = ops.random_actions(akeys, t, ts.observation.action_mask)
+        eaction = oracle.random_actions_batch(to_np(akeys), t, ets["action_mask"])
+        state, ts = env.step(state, action)
+        ets = oracle_auto_reset_step(oracle, gen_fn, est, eaction, tl)
+        assert_dicts_equal(state_to_np(state), est, f"d{depth} K{delay} step {t} state.")
+        assert_dicts_equal(timestep_to_np(ts), ets, f"d{depth} K{delay} step {t} timestep.")
+    (sess,) = env.unwrapped._sessions.values()
+    hits = int(to_np(sess.epochs.stash["hits"]).sum())
+    misses = int(to_np(sess.epochs.stash["misses"]).sum())
+    assert hits > 0 and hits + misses >= B * (steps // tl - 1), (hits, misses)
+    if delay > depth * tl:
+        assert misses > 0, "this schedule was meant to miss"
+    sess.drain()
