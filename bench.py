@@ -919,7 +919,7 @@ def main() -> None:
                     "policy": "masked uniform (rbg_random_actions): its own launch per step "
                               "(prefetch, inline_reset, no_auto_reset) or computed inside the "
                               "step launch from the state's own mask (prefetch_fused_policy: "
-                              "rbg_connector_rollout_prefetch with n_steps = 1, bit-identical)",
+                              "rbg_connector_step_gen with policy_keys, bit-identical)",
                     "variants": {"prefetch": v_pref, "inline_reset": v_inl,
                                  "prefetch_fused_policy": v_fus,
                                  "prefetch_fused_policy_2groups": v_grp, "no_auto_reset": v_off},

@@ -164,10 +164,17 @@ def test_native_generators_take_the_fused_path(rbg, name):
         raise AssertionError("generic auto-reset path taken")
 
     env.unwrapped._generic_auto_reset = refuse
-    state, ts = env.reset(_keys(rbg, 3, 16))
+    keys = _keys(rbg, 3, 16)
+    state, ts = env.reset(keys)
     for _ in range(5):
         state, ts = env.step(state, torch.zeros((16, 3), dtype=torch.int32, device="cuda"))
     assert int(to_np(state.step_count).max()) <= 2
+    # a single key keeps the unbatched shapes (jumanji's Connector.reset) and the same board
+    one_state, one_ts = env.unwrapped.reset(keys[5])
+    b_state, _ = env.unwrapped.reset(keys)
+    assert one_state.grid.shape == (8, 8) and one_ts.observation.grid.shape == (3, 8, 8)
+    assert (to_np(one_state.grid) == to_np(b_state.grid[5])).all()
+    assert (to_np(one_state.key) == to_np(b_state.key[5])).all()
 
 
 class _PythonGenerator:
