@@ -107,7 +107,11 @@ __device__ __forceinline__ void store_obs(const SubWave<LPB> &sw, const uint32_t
         // write-once stream: non-temporal keeps it from evicting the states in L2/Infinity Cache
         const v4i ov = {(int)(s01 & mx), (int)((s01 & my) >> 16), (int)(s23 & mz),
                         (int)((s23 & mw) >> 16)};
+#if defined(RBG_PROBE_PLAIN_OBS_STORES)  // developer probe (bench.py --mode stream on a variant build)
+        *reinterpret_cast<v4i *>(out) = ov;
+#else
         __builtin_nontemporal_store(ov, reinterpret_cast<v4i *>(out));
+#endif
         out += g.n;
         const u16x2 t01 = u01 - three, t23 = u23 - three;
         u01 = __builtin_elementwise_min(t01, (u16x2)(t01 + wrap));
