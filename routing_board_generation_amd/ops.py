@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _native as nat
+from .schedule import RefillSchedule
 
 StateBufs = Dict[str, torch.Tensor]
 TimestepBufs = Dict[str, torch.Tensor]
@@ -618,31 +619,40 @@ class EpochStash:
         a decision may lag by one refill)."""
         self.B, self.m, self.N, self.device = B, m, N, device
         self.gen, self._g = gen, _gen_ref(gen)
-        self.K = self.K0 = max(1, int(every))
         self.serial = bool(serial)
-        self.tick = 0
-        # serial: the launch tick behind which the next refill goes.  The first one follows the very
-        # first launch (the reset): every env's first successor is generated before any episode can
-        # end, instead of the early finishers of the first K steps running the generator inline
-        self._refill_after = 0
+        # when refills are queued (serial form; the first one follows the reset launch itself, so
+        # that no early finisher of the first K steps runs the generator inline): schedule.py
+        self.sched = RefillSchedule(every, B, adaptive=bool(adaptive) and self.serial)
+        self.K0 = self.sched.K0
         self.stash = alloc_stash(B, m, N, device, depth)
         self.struct = _stash_struct(self.stash, B, m, N)
         self._lib = nat.lib()
-        self.adaptive = bool(adaptive) and self.serial
+        self.adaptive = self.sched.adaptive
         if self.adaptive:
             self._miss_dev = torch.zeros((1,), dtype=torch.int64, device=device)
             self._miss_host = torch.zeros((1,), dtype=torch.int64).pin_memory()
-            self._miss_seen, self._calm = 0, 0
         if not self.serial:
             # consecutive refills may overlap each other (each keeps only a few waves busy)
             self._sides = [torch.cuda.Stream(device=device) for _ in range(2)]
             self._launched = [torch.cuda.Event() for _ in range(4)]
             self._done = [torch.cuda.Event() for _ in range(4)]
 
+    @property
+    def K(self) -> int:
+        return self.sched.K
+
+    @property
+    def tick(self) -> int:
+        return self.sched.tick
+
+    @property
+    def _refill_after(self) -> int:
+        return self.sched.refill_after
+
     def ready_delay(self) -> int:
         """Ticks from the current launch to the first one that may use what it requests."""
         if self.serial:
-            return self._refill_after + 1 - self.tick
+            return self.sched.ready_delay()
         K = self.K
         return K * (self.tick // K + 2) - self.tick
 
@@ -656,14 +666,7 @@ class EpochStash:
 
     def _adapt(self, stream: Optional[torch.cuda.Stream]) -> None:
         """Halve the period while misses keep coming, let it grow back after four calm refills."""
-        seen = int(self._miss_host[0])  # whatever has arrived (no synchronisation)
-        if seen - self._miss_seen > self.B // 64:
-            self.K, self._calm = max(self.K0 // 8, 1, self.K // 2), 0
-        elif seen == self._miss_seen:
-            self._calm += 1
-            if self._calm >= 4 and self.K < self.K0:
-                self.K, self._calm = min(self.K0, self.K * 2), 0
-        self._miss_seen = seen
+        self.sched.observe_misses(int(self._miss_host[0]))  # whatever has arrived (no sync)
         with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
             torch.sum(self.stash["misses"], dim=0, keepdim=True, out=self._miss_dev)
             self._miss_host.copy_(self._miss_dev, non_blocking=True)
@@ -671,15 +674,15 @@ class EpochStash:
     def after_launch(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Right after it: the last launch of an epoch queues the refill."""
         if self.serial:
-            if self.tick == self._refill_after:
+            if self.sched.refill_due():
                 sp = C.c_void_p(stream.cuda_stream) if stream is not None else _stream(self.device)
                 nat.check(self._lib.rbg_stash_refill_gen(self._g, self.B, self.m, self.N,
                                                          C.byref(self.struct), sp),
                           "rbg_stash_refill")
                 if self.adaptive:
                     self._adapt(stream)
-                self._refill_after = self.tick + self.K
-            self.tick += 1
+                self.sched.refill_queued()
+            self.sched.launched()
             return
         K, e = self.K, self.tick // self.K
         if self.tick % K == K - 1:
@@ -693,7 +696,7 @@ class EpochStash:
                                                      C.c_void_p(side.cuda_stream)),
                       "rbg_stash_refill")
             self._done[e % 4].record(side)
-        self.tick += 1
+        self.sched.launched()
 
     def drain(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Make `stream` wait for every refill in flight (before freeing the buffers)."""
