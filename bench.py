@@ -343,6 +343,7 @@ def cpu_rate(fn, units):
     return units / (time.perf_counter() - t0)
 
 
+WALK_REFILL_EVERY = 20  # ParallelRandomWalkGenerator.native_spec().refill["every"]
 GENERATION_TYPES = ("online_parallel_rw", "online_uniform", "online_seq_rw", "online_random_seed",
                     "offline_parallel_rw", "offline_seed_extension")
 
@@ -773,7 +774,7 @@ def main() -> None:
     # BASELINE configs[2] through the per-step API: every step = masked-uniform policy kernel +
     # connector_kernel (state in/out + full observation through HBM), auto-reset on.  The loop
     # reuses its buffers and prebuilt launch descriptors (ops.StepLoop).  Four variants:
-    #   prefetch     next-episode States generated ahead of time, one refill per 16 steps (rbg_stash),
+    #   prefetch     next-episode States generated ahead of time, one refill per 20 steps (rbg_stash),
     #                so a step launch never waits for a random walk           -> `value`
     #   inline       the walk of every finished env runs inside the step launch
     #   fused_policy prefetch + policy and step in one launch (rbg_connector_rollout, 1 step)
@@ -882,7 +883,7 @@ def main() -> None:
                 return in_runs / n, e0.elapsed_time(e1) / n
 
         if args.mode == "step-replay":
-            k_step, k_span = step_kernel_ms(16)
+            k_step, k_span = step_kernel_ms(WALK_REFILL_EVERY)
             ach = B * sb / (k_step * 1e-3) / 1e9
             if rank == 0:
                 print(json.dumps({"mode": "step-replay", "kernel": "connector_step_kernel",
@@ -896,11 +897,11 @@ def main() -> None:
                               **pure_stream(rbg, ops, torch, dev, m, N, sb, args.stream_batch,
                                             copy_gbs), "peak_measured": peaks}), flush=True)
             return
-        v_pref, k_pref = run_loop(16, False)
-        k_step, k_span = step_kernel_ms(16)
+        v_pref, k_pref = run_loop(WALK_REFILL_EVERY, False)
+        k_step, k_span = step_kernel_ms(WALK_REFILL_EVERY)
         v_inl, k_inl = run_loop(0, False)
-        v_fus, k_fus = run_loop(16, True)
-        v_grp, k_grp = run_loop(16, True, groups=2)
+        v_fus, k_fus = run_loop(WALK_REFILL_EVERY, True)
+        v_grp, k_grp = run_loop(WALK_REFILL_EVERY, True, groups=2)
         v_off, k_off = run_loop(0, False, auto_reset=False)
         api = {"functional": run_api(False, False), "functional_prefetch": run_api(True, False),
                "donate_prefetch": run_api(True, True),
@@ -959,7 +960,7 @@ def main() -> None:
                                          "launch gaps included, refills excluded; `bench.py "
                                          "--mode step-replay` runs only this, and its rocprofv3 "
                                          "kernel stats are in profiles/); span_with_refills_ms "
-                                         "amortises the one refill per 16 steps in; the whole "
+                                         "amortises the one refill per 20 steps in; the whole "
                                          "step incl. the policy launch is ms_per_step"}}
         # the same kernel as a pure stream (no env terminates, batch large enough to leave the
         # Infinity Cache): how close connector_kernel gets to the HBM roofline when neither resets

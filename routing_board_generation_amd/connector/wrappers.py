@@ -50,7 +50,7 @@ class VmapAutoResetWrapper(_Wrapper):
         generator for all the envs that restarted since the last one, instead of every step launch
         waiting for the generator runs of its own finished envs; results are identical with and
         without it.  prefetch_delay=None takes the generator's measured best
-        (ops.GeneratorSpec.refill: 16 steps for ParallelRandomWalk, 48 with two slots per env for
+        (ops.GeneratorSpec.refill: 20 steps for ParallelRandomWalk, 48 with two slots per env for
         SequentialRandomWalk / SeedExtension, none for Uniform and the offline dataset, whose
         "generation" is cheaper than a stash row copy).
         donate=True/False overrides the env's setting (Connector(donate=...))."""

@@ -30,7 +30,9 @@ class ParallelRandomWalkGenerator(Generator):
     def native_spec(self):
         from .. import _native as nat
 
-        return ops.GeneratorSpec(nat.GEN_PARALLEL_RW)
+        # one refill per 20 steps (fine sweep, DESIGN.md 4.2a: 12 / 16 / 20 / 24 / 28 / 32 steps ->
+        # 15.2 / 14.7 / 14.3 / 14.4 / 14.9 / 16.3 us per step at B = 4096)
+        return ops.GeneratorSpec(nat.GEN_PARALLEL_RW, refill={"every": 20})
 
 
 class ParallelRandomWalkPhiloxGenerator(Generator):
@@ -54,4 +56,4 @@ class ParallelRandomWalkPhiloxGenerator(Generator):
     def native_spec(self):
         from .. import _native as nat
 
-        return ops.GeneratorSpec(nat.GEN_PARALLEL_RW_PHILOX)
+        return ops.GeneratorSpec(nat.GEN_PARALLEL_RW_PHILOX, refill={"every": 20})
