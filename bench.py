@@ -365,12 +365,14 @@ def env_steps_by_generator(keys, m, N, steps, close=None):
             kw = dict(randomness=0.0, two_sided=True, extension_iterations=1, extension_steps=1e23,
                       number_of_boards=10000)
         gen = make_online_generator(name, m, N, **kw).native_spec()
-        sched = {"every": 16, "depth": 1, **gen.refill}
+        sched = {"every": 16, "depth": 1, "serial": True, "lead": 2, "streams": 2, **gen.refill}
         st, ts = ops.alloc_state(B, m, N, dev), ops.alloc_timestep(B, m, N, dev)
         loop = ops.StepLoop(st, ts, keys, refill_every=sched["every"], fuse_policy=True, gen=gen,
-                            stash_depth=sched["depth"])
+                            stash_depth=sched["depth"], serial_refill=sched["serial"],
+                            refill_lead=sched["lead"], refill_streams=sched["streams"])
         loop.reset(keys)
-        warm = max(60, 2 * sched["every"])
+        # (rolling refills: the pipeline of refills in flight is full after lead + 1 epochs)
+        warm = max(60, (2 if sched["serial"] else sched["lead"] + 2) * sched["every"])
         for t in range(warm):
             loop.step(t)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -389,6 +391,9 @@ def env_steps_by_generator(keys, m, N, steps, close=None):
         us = e0.elapsed_time(e1) / steps * 1e3
         rows[name] = {"us_per_step": us, "env_steps_per_s": B / us * 1e6,
                       "stash": ({"refill_every": sched["every"], "slots_per_env": sched["depth"],
+                                 **({} if sched["serial"] else
+                                    {"rolling": True, "lead_epochs": sched["lead"],
+                                     "generator_streams": sched["streams"]}),
                                  "hits": int(loop.stash["hits"].sum().item()),
                                  "misses": int(loop.stash["misses"].sum().item())}
                                 if sched["every"] else "none (the generator runs inside the step "

@@ -224,7 +224,7 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  * the envs that restarted recently (a throughput-shaped batch of walks) instead of by every step
  * launch for its own few finished envs (a launch that lasts as long as its longest walk); the
  * step then copies 1.3 KB instead of walking.
- *   depth       slots per env, 1 .. 4; slot s of env b is row s * B + b of every array below
+ *   depth       slots per env, 1 .. 8; slot s of env b is row s * B + b of every array below
  *   next        a full rbg_state of depth * B rows: next[r] = reset(split(tag[r])[0])
  *   tag         uint32 [depth*B][2]: the State.key next[r] was generated for (zero-initialised)
  *   ready_at    int32 [depth*B]: first launch tick that may consume the row (zero-initialised)
@@ -232,6 +232,14 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  *   hits        int32 [B], nullable: resets served from the stash (diagnostics; caller zeroes)
  *   misses      int32 [B], nullable: resets of a stash-backed launch that had to run the generator
  *               inline (caller zeroes; a host that sees them grow refills more often)
+ *   inflight    int32 [depth*B], nullable (zero-initialised): 1 while a listed refill is
+ *               generating the row.  Needed when refills overlap each other (rolling refills on
+ *               side streams, below): rbg_stash_list skips such rows, so that nothing is generated
+ *               twice and two producers never write one row at the same time
+ *   far_key     uint32 [B][2], nullable: the farthest key env b holds a request for.  With it a
+ *               restart that took its State from the stash makes its one new request --
+ *               f(far) into the row it consumed -- without re-deriving the chain (deep stashes:
+ *               up to 14 dependent Threefry evaluations otherwise, on the wave the launch waits for)
  *   scratch     int32 [depth*B + 1], nullable: work area of rbg_stash_refill_gen.  With it the
  *               refill first lists the rows that need a generator run and then packs them densely
  *               into wavefronts (SeedExtension runs four boards per wavefront: requests scattered
@@ -265,6 +273,8 @@ typedef struct rbg_stash {
   int32_t *hits;
   int32_t *misses;
   int32_t *scratch;
+  int32_t *inflight;
+  uint32_t *far_key;
   int32_t depth;
 } rbg_stash;
 
@@ -460,6 +470,23 @@ typedef struct rbg_step_call {
   void *stream;
 } rbg_step_call;
 int rbg_connector_step_call(const rbg_step_call *call);
+
+/* The two halves of a refill, for hosts that keep SEVERAL refills in flight beside the stepping
+ * stream ("rolling refills": a SeedExtension / SequentialRandomWalk refill lasts 0.4-1.8 ms
+ * whatever its row count -- as long as its slowest board -- but leaves most of the chip idle, and
+ * neither it nor the step launches are slowed much by the other):
+ *   rbg_stash_list            lists the rows with a pending request (tag != refill_key) that no
+ *                             earlier refill is still generating into stash->scratch ([0] = count)
+ *                             and marks them in stash->inflight.  Calls must be stream-ordered
+ *                             among themselves (one "listing" stream); each in-flight refill
+ *                             needs a scratch area of its own (pass a copy of the struct).
+ *   rbg_stash_refill_listed   generates exactly the listed rows and releases them.
+ * Ordering contract (host, events): a list call follows the launches whose requests it is to
+ * see; its producer follows it; the launch that may consume a row (ready_at) follows the
+ * producer.  Nothing else: requests written while a refill runs are simply seen by a later one. */
+int rbg_stash_list(int B, int m, int N, const rbg_stash *stash, void *stream);
+int rbg_stash_refill_listed(const rbg_generator *generator, int B, int m, int N,
+                            const rbg_stash *stash, void *stream);
 
 /* rbg_stash_refill with the generator's own producer: next[r] = generator(split(refill_key[r])[0])
  * for every row with tag[r] != refill_key[r]. */

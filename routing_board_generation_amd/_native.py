@@ -53,7 +53,8 @@ class RolloutStats(C.Structure):
 class Stash(C.Structure):
     _fields_ = [("next", State), ("tag", C.c_void_p), ("ready_at", C.c_void_p),
                 ("refill_key", C.c_void_p), ("hits", C.c_void_p), ("misses", C.c_void_p),
-                ("scratch", C.c_void_p), ("depth", C.c_int32)]
+                ("scratch", C.c_void_p), ("inflight", C.c_void_p), ("far_key", C.c_void_p),
+                ("depth", C.c_int32)]
 
 
 class Generator(C.Structure):
@@ -145,6 +146,9 @@ SIGNATURES = {
                                          C.POINTER(Timestep), C.POINTER(Stash), C.c_int, C.c_int,
                                          C.c_void_p]),
     "rbg_connector_step_call": (C.c_int, [C.POINTER(StepCall)]),
+    "rbg_stash_list": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Stash), C.c_void_p]),
+    "rbg_stash_refill_listed": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(Stash), C.c_void_p]),
     "rbg_stash_refill_gen": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,
                                        C.POINTER(Stash), C.c_void_p]),
     "rbg_connector_rollout_gen": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,

@@ -143,7 +143,8 @@ int fill_gen(const rbg_generator *gen, int m, int N, GenSpec *gs, int *prefix_co
       p.rnd_mode = !(gen->randomness > 0.0f) ? 0 : (gen->randomness >= 1.0f ? 1 : 2);
       p.bfs_last = 0;  // a State never shows the last re-routing
       p.half = m / 2;
-      gs->extra_words = se_extra_words(words, m * m);
+      gs->extra_words = se_extra_words(words, m * m, /*bfs_possible=*/p.iterations > 1);
+      p.extra_words = gs->extra_words;
       return 0;
     }
     case RBG_GEN_DATASET: {
@@ -333,6 +334,7 @@ int rbg_seed_extension_generate(const uint32_t *keys, int B, int m, int N, int s
   p.rnd_mode = !(randomness > 0.0f) ? 0 : (randomness >= 1.0f ? 1 : 2);
   p.bfs_last = solved_grid != nullptr;  // only the solved board can see the last re-routing
   p.half = m / 2;
+  p.extra_words = se_extra_words(a.g.words, a.g.n, p.bfs_last || p.iterations > 1);
   // lanes per board: lane w owns wire w; fewer, fuller waves as long as the workgroup's LDS fits
   int lpb = 16;
   while (lpb < N) lpb *= 2;
@@ -340,7 +342,7 @@ int rbg_seed_extension_generate(const uint32_t *keys, int B, int m, int N, int s
   size_t lds = 0;
   for (;;) {
     const size_t per_board =
-        (size_t)((a.g.words + 3) & ~3) + (size_t)(4 * lpb) + (size_t)se_extra_words(a.g.words, a.g.n);
+        (size_t)((a.g.words + 3) & ~3) + (size_t)(4 * lpb) + (size_t)p.extra_words;
     lds = (size_t)wpb * (size_t)(kWaveSize / lpb) * per_board * sizeof(uint32_t);
     if (lds <= 64u * 1024u) break;
     if (lpb < kWaveSize) lpb *= 2; else if (wpb > 1) wpb /= 2; else break;
@@ -425,6 +427,8 @@ static int fill_stash(const rbg_stash *stash, StashPtrs *out, const char *who) {
   out->hits = stash->hits;
   out->misses = stash->misses;
   out->scratch = stash->scratch;
+  out->inflight = stash->inflight;
+  out->far_key = stash->far_key;
   out->depth = stash->depth;
   if (stash->depth < 1 || stash->depth > kMaxStashDepth) {
     snprintf(g_err, sizeof(g_err), "%s: stash depth must be in [1, %d]", who, kMaxStashDepth);
@@ -510,8 +514,10 @@ int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream) 
   return rbg_stash_refill_gen(nullptr, B, m, N, stash, stream);
 }
 
-int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
-                         const rbg_stash *stash, void *stream) {
+// mode 0: scan every row (listing SeedExtension's first when a scratch area is given: dense
+// packing); 1: list only; 2: generate the listed rows
+static int stash_refill_impl(const rbg_generator *generator, int B, int m, int N,
+                             const rbg_stash *stash, void *stream, int mode) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_stash_refill: B < 0");
   RefillArgs a;
   memset(&a, 0, sizeof(a));
@@ -554,11 +560,24 @@ int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
   if (!stash) return fail(RBG_E_NULL, "rbg_stash_refill: NULL stash");
   if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_stash_refill")) return rc;
+  if (mode != 0 && !a.stash.scratch)
+    return fail(RBG_E_NULL, "rbg_stash_list / rbg_stash_refill_listed: the stash has no scratch area");
   a.B = B * stash->depth;  // the kernel works on rows
   a.N = N;
   const int envs_per_block = wpb * (kWaveSize / lpb);
   const dim3 grid((a.B + envs_per_block - 1) / envs_per_block), block(kWaveSize * wpb);
   hipStream_t st = (hipStream_t)stream;
+  const bool list_here = mode == 1 || (mode == 0 && kind == kGenSeedExt && a.stash.scratch &&
+                                       lpb < kWaveSize);
+  if (list_here) {
+    // several boards per wavefront: list the requested rows first, then pack them densely
+    if (int rc = check_hip(hipMemsetAsync(a.stash.scratch, 0, sizeof(int32_t), st),
+                           "rbg_stash_refill")) return rc;
+    if (mode == 0) a.stash.inflight = nullptr;  // one stream, nothing overlaps: no claims
+    hipLaunchKernelGGL(stash_list_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
+    if (mode == 1) return check_hip(hipGetLastError(), "rbg_stash_list");
+  }
+  a.listed = (list_here || mode == 2) ? 1 : 0;
   if (kind == kGenUniform) {
     hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenUniform>), grid, block, lds, st, a);
   } else if (kind == kGenSeqRw) {
@@ -572,19 +591,20 @@ int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
       hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenPhilox>), grid, block, lds, st, a);
     }
   } else if (kind == kGenSeedExt) {
-    if (a.stash.scratch && lpb < kWaveSize) {
-      // several boards per wavefront: list the requested rows first, then pack them densely
-      if (int rc = check_hip(hipMemsetAsync(a.stash.scratch, 0, sizeof(int32_t), st),
-                             "rbg_stash_refill")) return rc;
-      hipLaunchKernelGGL(stash_list_kernel, dim3((a.B + 255) / 256), dim3(256), 0, st, a);
-      a.listed = 1;
-    }
     if (lpb == 16) {
       hipLaunchKernelGGL((stash_refill_gen_kernel<16, kGenSeedExt>), grid, block, lds, st, a);
     } else if (lpb == 32) {
       hipLaunchKernelGGL((stash_refill_gen_kernel<32, kGenSeedExt>), grid, block, lds, st, a);
     } else {
       hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenSeedExt>), grid, block, lds, st, a);
+    }
+  } else if (a.listed) {  // the walk from a list (rolling refills)
+    if (lpb == 16) {
+      hipLaunchKernelGGL((stash_refill_gen_kernel<16, kGenPrw>), grid, block, lds, st, a);
+    } else if (lpb == 32) {
+      hipLaunchKernelGGL((stash_refill_gen_kernel<32, kGenPrw>), grid, block, lds, st, a);
+    } else {
+      hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenPrw>), grid, block, lds, st, a);
     }
   } else if (lpb == 16) {
     hipLaunchKernelGGL(stash_refill_kernel<16>, grid, block, lds, st, a);
@@ -594,6 +614,20 @@ int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
     hipLaunchKernelGGL(stash_refill_kernel<64>, grid, block, lds, st, a);
   }
   return check_hip(hipGetLastError(), "rbg_stash_refill");
+}
+
+int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
+                         const rbg_stash *stash, void *stream) {
+  return stash_refill_impl(generator, B, m, N, stash, stream, 0);
+}
+
+int rbg_stash_list(int B, int m, int N, const rbg_stash *stash, void *stream) {
+  return stash_refill_impl(nullptr, B, m, N, stash, stream, 1);
+}
+
+int rbg_stash_refill_listed(const rbg_generator *generator, int B, int m, int N,
+                            const rbg_stash *stash, void *stream) {
+  return stash_refill_impl(generator, B, m, N, stash, stream, 2);
 }
 
 int rbg_connector_observe(int B, int m, int N, const rbg_state *state,

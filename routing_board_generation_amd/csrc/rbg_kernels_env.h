@@ -39,6 +39,14 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 #if defined(RBG_PROBE_STEP_TIMES)  // developer probe (tools/probe_step.py --times)
   const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
 #endif
+  // Rolling refills (stash.inflight given: refills run beside the step launches): the step's
+  // waves outrank the refill's in issue arbitration.  A refill wave is the oldest wave on its
+  // SIMD for a millisecond and wins every cycle it is ready in; at equal priority a SeedExtension
+  // refill makes the step launches it overlaps 3-7x longer (13 -> 30-105 us), at priority 1 they
+  // take 17-18 us and the refill, which has slack, takes the rest.
+  if constexpr (MODE == kModeStep) {
+    if (a.stash.inflight) __builtin_amdgcn_s_setprio(1);
+  }
   const int lane = threadIdx.x & (kWaveSize - 1);
   const SubWave<64> sw(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -143,7 +151,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
       key = regenerate_kind<64, KIND>(sw, board, W, g, N, rk, ag, a.gen);
     }
     step_count = 0;
-    request_refill<KIND>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+    request_refill<KIND>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay, row, true, probe.far);
     const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
     store_state(sw, board, g, N, b, ag, step_count, key, a.out);
     write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
@@ -228,6 +236,12 @@ __global__ void stash_list_kernel(RefillArgs a) {
     const uint2 want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)r]);
     const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)r]);
     need = want.x != have.x || want.y != have.y;
+    // a row that an earlier, still running refill is generating is left alone: two producers
+    // never write one row at a time, and nothing is generated twice (include/rbg_prw.h)
+    if (need && a.stash.inflight) {
+      need = a.stash.inflight[r] == 0;
+      if (need) a.stash.inflight[r] = 1;
+    }
   }
   const uint64_t m = __ballot(need);
   if (m == 0ull) return;
@@ -272,7 +286,13 @@ __global__ __launch_bounds__(kBlock) void stash_refill_gen_kernel(RefillArgs a) 
   const Key2 next_key = regenerate_kind<LPB, KIND>(sw, board, W, g, a.N, rk, ag, a.gen);
   if (need) {
     store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
-    if (sw.l == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
+    if (sw.l == 0) {
+      *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
+      if (a.listed && a.stash.inflight) {
+        __threadfence();  // whoever sees the row released also sees its tag
+        a.stash.inflight[b] = 0;
+      }
+    }
   }
 }
 

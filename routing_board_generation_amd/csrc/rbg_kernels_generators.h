@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void seed_extension_kernel(SeArgs args) {
   // boards past the end of the batch redo the wave's first board and store nothing
   const bool valid = first + sw.h < a.B;
   const int b = valid ? first + sw.h : first;
-  const int per_board = slab_words<LPB>(g) + se_extra_words(g.words, g.n);
+  const int per_board = slab_words<LPB>(g) + args.p.extra_words;
   uint32_t *board = g_lds + (wib * kSubs + sw.h) * per_board;
   uint32_t *scr = board + board_words(g);
   uint32_t *xtra = board + slab_words<LPB>(g);

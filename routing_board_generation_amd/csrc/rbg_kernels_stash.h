@@ -16,9 +16,11 @@ struct StashPtrs {
   int32_t *hits;         // [B] nullable diagnostics: resets served from the stash
   int32_t *misses;       // [B] nullable: resets that ran the generator inline although a stash exists
   int32_t *scratch;      // [depth*B + 1] nullable: [0] = number of listed rows, [1..] = the rows
+  int32_t *inflight;     // [depth*B] nullable: 1 while a listed refill is generating the row
+  uint32_t *far_key;     // [B][2] nullable: the farthest key env b has requested a row for
   int depth;             // 1 .. kMaxStashDepth
 };
-constexpr int kMaxStashDepth = 4;
+constexpr int kMaxStashDepth = 8;
 
 // Row of the stash that holds the successor of the episode with State.key `key`, or -1.
 __device__ __forceinline__ int stash_lookup(const StashPtrs &st, int B, int b, Key2 key,
@@ -40,15 +42,17 @@ __device__ __forceinline__ int stash_lookup(const StashPtrs &st, int B, int b, K
 struct StashProbe {
   uint2 tag;
   int ready_at;
+  uint2 far;  // lane 0: StashPtrs::far_key of the env (0 without one)
 };
 __device__ __forceinline__ StashProbe stash_probe_issue(const StashPtrs &st, int B, int b,
                                                         int lane) {
-  StashProbe p = {make_uint2(0u, 0u), 0x7FFFFFFF};
+  StashProbe p = {make_uint2(0u, 0u), 0x7FFFFFFF, make_uint2(0u, 0u)};
   if (st.tag && lane < st.depth) {
     const int r = lane * B + b;
     p.tag = *reinterpret_cast<const uint2 *>(&st.tag[2 * (size_t)r]);
     p.ready_at = st.ready_at[r];
   }
+  if (st.far_key && lane == 0) p.far = *reinterpret_cast<const uint2 *>(&st.far_key[2 * (size_t)b]);
   return p;
 }
 __device__ __forceinline__ int stash_probe_row(const StashPtrs &st, const StashProbe &p, int B,
@@ -115,14 +119,41 @@ __device__ __forceinline__ void stash_row_commit(const SubWave<64> &sw, uint32_t
 // the one with State.key k; no generator has to run to know it.  Rows that already carry one of those requests
 // keep it (and their ready_at); the others -- just consumed, stale, or never used -- take the
 // missing ones.  depth 1: the one row is requested for `key`.  Called by the whole sub-wave.
+// `hit_row` >= 0: the restart consumed that row of the stash.  With a far key per env
+// (StashPtrs::far_key, deep stashes) that is all the bookkeeping there is: the rows other than
+// the consumed one already carry the requests of the chain (by induction: every restart of the
+// env goes through here, and a restart that found no row takes the general rule below), so the
+// consumed row takes the one new request, f(far), and far moves on -- two Threefry evaluations
+// and two stores instead of up to 2 (D - 1) evaluations and D^2 compares on the wave the launch
+// is waiting for.  `far_in` = the env's far key as fetched with the early probe (lane 0).
 template <int KIND, int LPB>
 __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const StashPtrs &st, int B,
-                                               int b, Key2 key, int ready_at) {
+                                               int b, Key2 key, int ready_at, int hit_row = -1,
+                                               bool have_far = false,
+                                               uint2 far_in = make_uint2(0u, 0u)) {
   if (!st.refill_key) return;
   if (st.depth == 1) {
     if (sw.l == 0) {
       *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)b]) = make_uint2(key.a, key.b);
       st.ready_at[b] = ready_at;
+    }
+    return;
+  }
+  if (st.far_key && hit_row >= 0) {  // (uniform in the sub-wave)
+    Key2 far;
+    if (have_far) {
+      far.a = sw.bcast(far_in.x, 0);
+      far.b = sw.bcast(far_in.y, 0);
+    } else {
+      const uint2 f = *reinterpret_cast<const uint2 *>(&st.far_key[2 * (size_t)b]);
+      far.a = f.x;
+      far.b = f.y;
+    }
+    const Key2 nf = next_state_key<LPB, KIND>(sw, far);
+    if (sw.l == 0) {
+      *reinterpret_cast<uint2 *>(&st.refill_key[2 * (size_t)hit_row]) = make_uint2(nf.a, nf.b);
+      st.ready_at[hit_row] = ready_at;
+      *reinterpret_cast<uint2 *>(&st.far_key[2 * (size_t)b]) = make_uint2(nf.a, nf.b);
     }
     return;
   }
@@ -160,6 +191,12 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
         st.ready_at[r] = ready_at;
         row_used |= 1u << s;
       }
+    }
+    if (st.far_key) {
+      Key2 far = want[0];
+#pragma unroll
+      for (int j = 1; j < kMaxStashDepth; ++j) far = j < D ? want[j] : far;
+      *reinterpret_cast<uint2 *>(&st.far_key[2 * (size_t)b]) = make_uint2(far.a, far.b);
     }
   }
 }

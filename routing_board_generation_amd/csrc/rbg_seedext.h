@@ -56,16 +56,23 @@ struct SeParams {
   int bfs_last;       // run optimise_wire after the last extension too (solved board wanted)
   int half;           // m / 2: candidate cells per side
   int seed_only;      // return_seeded_board(key): the key IS the seed key, nothing else runs
+  int extra_words;    // se_extra_words() as the host sized the launch's LDS with
 };
 
 // extra LDS words per board after the slab of rbg_device.h:
 //   extension: idx bytes [4 + n + margin] + rnd bytes [4 + n + margin + 4] (the byte pointers of
 //   phase A run from two positions before to a few past their arrays);  seeding: nc sort keys;
 //   BFS: claim words [padded board] + FIFO u16 [n + 2]
-__host__ __device__ inline int se_extra_words(int words_padded, int n) {
-  const int bfs = ((words_padded + 3) & ~3) + (n + 2 + 1) / 2;
+// `bfs` = optimise_wire can run at all (a solved board is wanted or another extension iteration
+// follows): without it a 16x16 board needs 0.55 instead of 2.1 KB here, which is what lets two
+// refill launches and the step launches share a CU's LDS.
+__host__ __device__ inline int se_extra_words(int words_padded, int n, bool bfs_possible = true) {
+  const int bfs = bfs_possible ? ((words_padded + 3) & ~3) + (n + 2 + 1) / 2 : 0;
   const int ext = (2 * (n + kSeMargin) + 12 + 3) / 4;
-  return (((bfs > ext ? bfs : ext) + 3) & ~3) + 4;
+  const int seed = (n + 3) / 4;  // sort keys of the (m / 2)^2 candidate cells
+  int w = bfs > ext ? bfs : ext;
+  w = w > seed ? w : seed;
+  return ((w + 3) & ~3) + 4;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,10 +30,14 @@ class SeedExtensionGenerator(Generator):
         from .. import _native as nat
 
         # random_seed_generator.py:36-37: generate_starts_ends(key) with its defaults
-        # (refill: as for SequentialRandomWalk -- a launch of ~1.4 ms whatever its row count)
+        # (refill: a launch of 1.4-2 ms whatever its row count -- rolling refills beside the
+        # stepping stream, three in flight, every entry requested seven episodes ahead: 18-28 us
+        # per step depending on how the refills happen to overlap, against 42-47 in line;
+        # DESIGN.md 4.2a)
         return ops.GeneratorSpec(nat.GEN_SEED_EXTENSION, randomness=0.0, two_sided=True,
                                  extension_iterations=1, max_extension_steps=ops.INT32_MAX,
-                                 refill={"every": 48, "depth": 2, "adaptive": True, "record_stash": True})
+                                 refill={"every": 56, "depth": 8, "serial": False, "lead": 3,
+                                         "streams": 3, "record_stash": True})
 
 
 RandomSeedGenerator = SeedExtensionGenerator

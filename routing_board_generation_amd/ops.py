@@ -510,11 +510,12 @@ def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
 
 
 # ------------------------------------------------------------------------------------- prefetch
-def alloc_stash(B: int, m: int, N: int, device, depth: int = 1) -> dict:
+def alloc_stash(B: int, m: int, N: int, device, depth: int = 1, rolling: bool = False) -> dict:
     """Buffers of include/rbg_prw.h::rbg_stash (tag / ready_at / refill_key / hits zeroed);
-    `depth` slots per env, slot s of env b in row s * B + b."""
-    if depth not in (1, 2, 3, 4):
-        raise ValueError("stash depth must be in [1, 4]")
+    `depth` slots per env, slot s of env b in row s * B + b.  rolling: also the in-flight marks
+    of refills that overlap each other and the step launches (EpochStash(serial=False))."""
+    if depth not in range(1, 9):
+        raise ValueError("stash depth must be in [1, 8]")
     R = depth * B
     return {"next": alloc_state(R, m, N, device),
             "tag": torch.zeros((R, 2), dtype=torch.uint32, device=device),
@@ -523,6 +524,8 @@ def alloc_stash(B: int, m: int, N: int, device, depth: int = 1) -> dict:
             "hits": torch.zeros((B,), dtype=torch.int32, device=device),
             "misses": torch.zeros((B,), dtype=torch.int32, device=device),
             "scratch": torch.zeros((R + 1,), dtype=torch.int32, device=device),
+            "inflight": (torch.zeros((R,), dtype=torch.int32, device=device) if rolling else None),
+            "far_key": torch.zeros((B, 2), dtype=torch.uint32, device=device),
             "depth": depth}
 
 
@@ -540,9 +543,14 @@ def _stash_struct(stash: dict, B: int, m: int, N: int) -> nat.Stash:
     scratch = stash.get("scratch")
     if scratch is not None:
         _check(scratch, torch.int32, (R + 1,), "stash.scratch")
+    inflight, far = stash.get("inflight"), stash.get("far_key")
+    if inflight is not None:
+        _check(inflight, torch.int32, (R,), "stash.inflight")
+    if far is not None:
+        _check(far, torch.uint32, (B, 2), "stash.far_key")
     return nat.Stash(nxt, stash["tag"].data_ptr(), stash["ready_at"].data_ptr(),
                      stash["refill_key"].data_ptr(), stash["hits"].data_ptr(), _ptr(misses),
-                     _ptr(scratch), depth)
+                     _ptr(scratch), _ptr(inflight), _ptr(far), depth)
 
 
 def connector_reset_prefetch(keys: torch.Tensor, m: int, N: int, stash: dict, tick: int,
@@ -594,29 +602,39 @@ def stash_refill(stash: dict, m: int, gen: Optional[GeneratorSpec] = None) -> No
 
 class EpochStash:
     """Host side of the stash protocol in its epoch form: launches are numbered (ticks) and
-    grouped in epochs of K; ONE rbg_stash_refill runs after the last launch of each epoch.
+    grouped in epochs of K; ONE refill is queued after the last launch of each epoch.
 
     serial=True (default): the refill is queued on the launches' own stream, so an entry
     requested in epoch e is usable from the first tick of epoch e + 1, and no events are needed.
-    Measured at B = 4096 this beats overlapping the refill on a side stream (below): a refill
-    alone takes ~25 us per epoch, whereas one that shares the SIMDs with the step launches slows
-    each of them down and costs ~60 us of main-stream time per epoch.
+    For the walk (a refill of ~30 us) this beats any overlap: a refill that shares the GPU with
+    the step launches slows each of them down by more than it takes alone.
 
-    serial=False: the refill runs on a side stream and must be complete before the first launch
-    of epoch e + 2 (one stream event per epoch); entries are usable from tick K * (e + 2) on."""
+    serial=False ("rolling refills"): the refills run beside the stepping stream -- rows listed on
+    one listing stream (rbg_stash_list, which also claims them so that overlapping refills never
+    generate a row twice), generated on `streams` generator streams used in turn
+    (rbg_stash_refill_listed) -- and an entry requested in epoch e is usable from the first tick
+    of epoch e + `lead`, which the stepping stream makes sure of with one event wait per epoch.
+    This is for the generators whose refill lasts as long as its slowest board whatever its row
+    count (SeedExtension 1.4-1.8 ms, SequentialRandomWalk 0.4-0.5 ms) while leaving most of the
+    chip idle: with one or two of them always in flight, generation keeps up with the ~85 boards
+    per step that 4096 envs consume, at the price of ~6 us per step launch (two queues active).
+    It needs lead time: lead * K steps for the refill to finish, so depth - 1 episodes must
+    outlast (lead + 1) * K steps (tools/probe_overlap.py).  The requests of the
+    reset launch are served by one refill on the stepping stream itself (usable from tick 1)."""
 
     def __init__(self, B: int, m: int, N: int, device, every: int, serial: bool = True,
                  depth: int = 1, gen: Optional[GeneratorSpec] = None,
-                 adaptive: bool = False) -> None:
-        """depth=2: two slots per env, every entry requested a whole episode before it is needed
-        (include/rbg_prw.h::rbg_stash) -- for launches of many steps (connector_rollout).
+                 adaptive: bool = False, lead: int = 2, streams: int = 2) -> None:
+        """depth: slots per env (include/rbg_prw.h::rbg_stash): every entry is requested
+        depth - 1 whole episodes before it is needed.
         gen: the generator whose producer refills the stash (None = ParallelRandomWalk).
         adaptive (serial only): watch the stash's miss counter and refill more often when
         episodes turn out shorter than the refill period -- a miss runs the generator inside the
         step launch, which for SequentialRandomWalk / SeedExtension stalls that launch for
         0.1-1 ms.  The period only moves between `every` / 8 and `every`; results never depend
         on it.  The counter travels to pinned host memory asynchronously (no synchronisation:
-        a decision may lag by one refill)."""
+        a decision may lag by one refill).
+        lead, streams (serial=False only): see the class docstring."""
         self.B, self.m, self.N, self.device = B, m, N, device
         self.gen, self._g = gen, _gen_ref(gen)
         self.serial = bool(serial)
@@ -624,18 +642,36 @@ class EpochStash:
         # that no early finisher of the first K steps runs the generator inline): schedule.py
         self.sched = RefillSchedule(every, B, adaptive=bool(adaptive) and self.serial)
         self.K0 = self.sched.K0
-        self.stash = alloc_stash(B, m, N, device, depth)
+        self.stash = alloc_stash(B, m, N, device, depth, rolling=not self.serial)
         self.struct = _stash_struct(self.stash, B, m, N)
         self._lib = nat.lib()
         self.adaptive = self.sched.adaptive
         if self.adaptive:
             self._miss_dev = torch.zeros((1,), dtype=torch.int64, device=device)
             self._miss_host = torch.zeros((1,), dtype=torch.int64).pin_memory()
+        self.fell_back = False
         if not self.serial:
-            # consecutive refills may overlap each other (each keeps only a few waves busy)
-            self._sides = [torch.cuda.Stream(device=device) for _ in range(2)]
-            self._launched = [torch.cuda.Event() for _ in range(4)]
-            self._done = [torch.cuda.Event() for _ in range(4)]
+            # a stash that misses in rolling form (episodes much shorter than the lead it was
+            # sized for) falls back to the serial, miss-adaptive form for good: _watch_misses
+            self._miss_dev = torch.zeros((1,), dtype=torch.int64, device=device)
+            self._miss_host = torch.zeros((1,), dtype=torch.int64).pin_memory()
+            self._miss_seen = 0
+            self.lead = max(2, int(lead))
+            ring = self.lead + 1
+            # (no stream of its own for the listing: HIP multiplexes streams onto 4 hardware
+            # queues, and the stepping stream + up to 3 generator streams use them up; the list
+            # launches are ordered among themselves by events instead)
+            self._gen_streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(streams)))]
+            self._launched = [torch.cuda.Event() for _ in range(ring)]
+            self._listed = [torch.cuda.Event() for _ in range(ring)]
+            self._done = [torch.cuda.Event() for _ in range(ring)]
+            # every refill in flight lists its rows into a scratch area of its own
+            self._scratch = [torch.zeros_like(self.stash["scratch"]) for _ in range(ring)]
+            self._structs = []
+            for sc in self._scratch:
+                st = nat.Stash.from_buffer_copy(self.struct)
+                st.scratch = sc.data_ptr()
+                self._structs.append(st)
 
     @property
     def K(self) -> int:
@@ -649,20 +685,28 @@ class EpochStash:
     def _refill_after(self) -> int:
         return self.sched.refill_after
 
+    def _epoch(self) -> int:
+        """Rolling form: tick 0 is the reset (served by a refill of its own), epoch e covers the
+        ticks 1 + e K .. (e + 1) K."""
+        return (self.tick - 1) // self.K
+
     def ready_delay(self) -> int:
         """Ticks from the current launch to the first one that may use what it requests."""
         if self.serial:
             return self.sched.ready_delay()
-        K = self.K
-        return K * (self.tick // K + 2) - self.tick
+        if self.tick == 0:
+            return 1
+        return 1 + self.K * (self._epoch() + self.lead) - self.tick
 
     def before_launch(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Right before a reset/step launch on `stream` (default: torch's current stream)."""
-        if self.serial:
+        if self.serial or self.tick == 0:
             return
-        K, e = self.K, self.tick // self.K
-        if self.tick % K == 0 and e >= 2:  # first launch of epoch e needs the refill of epoch e-2
-            (stream or torch.cuda.current_stream(self.device)).wait_event(self._done[(e - 2) % 4])
+        e = self._epoch()
+        if (self.tick - 1) % self.K == 0 and e >= self.lead:
+            # the first launch of epoch e may consume what the refill of epoch e - lead generated
+            (stream or torch.cuda.current_stream(self.device)).wait_event(
+                self._done[(e - self.lead) % len(self._done)])
 
     def _adapt(self, stream: Optional[torch.cuda.Stream]) -> None:
         """Halve the period while misses keep coming, let it grow back after four calm refills."""
@@ -671,10 +715,35 @@ class EpochStash:
             torch.sum(self.stash["misses"], dim=0, keepdim=True, out=self._miss_dev)
             self._miss_host.copy_(self._miss_dev, non_blocking=True)
 
+    def _watch_misses(self, stream: torch.cuda.Stream) -> None:
+        """Rolling form, once per epoch: the stash's miss counter travels to pinned host memory
+        without synchronising; if it grew by more than batch / 64 since the last look the lead
+        time this stash was sized for does not hold (short episodes: a trained policy), and every
+        miss stalls a step launch for a board's latency -- so the stepping stream waits for the
+        refills in flight once and the stash carries on in the serial, miss-adaptive form."""
+        seen = int(self._miss_host[0])
+        if seen - self._miss_seen > max(1, self.B // 64):
+            self.drain(stream)
+            with torch.cuda.stream(stream):
+                # every producer has finished: a row is consistent with its tag, so rows asked for
+                # under the rolling form's long lead are usable as soon as their key comes up
+                self.stash["ready_at"].zero_()
+            self.serial = self.fell_back = True
+            self.sched.adaptive = self.adaptive = True
+            self.sched.K = self.sched.K0 = min(self.sched.K0, 48)
+            self.sched.refill_after = self.sched.tick  # a refill right behind this launch
+            return
+        self._miss_seen = seen
+        with torch.cuda.stream(stream):
+            torch.sum(self.stash["misses"], dim=0, keepdim=True, out=self._miss_dev)
+            self._miss_host.copy_(self._miss_dev, non_blocking=True)
+
     def after_launch(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Right after it: the last launch of an epoch queues the refill."""
-        if self.serial:
-            if self.sched.refill_due():
+        if not self.serial and self.tick > 0 and (self.tick - 1) % self.K == self.K - 1:
+            self._watch_misses(stream or torch.cuda.current_stream(self.device))
+        if self.serial or self.tick == 0:
+            if self.tick == 0 or self.sched.refill_due():
                 sp = C.c_void_p(stream.cuda_stream) if stream is not None else _stream(self.device)
                 nat.check(self._lib.rbg_stash_refill_gen(self._g, self.B, self.m, self.N,
                                                          C.byref(self.struct), sp),
@@ -684,18 +753,23 @@ class EpochStash:
                 self.sched.refill_queued()
             self.sched.launched()
             return
-        K, e = self.K, self.tick // self.K
-        if self.tick % K == K - 1:
+        if (self.tick - 1) % self.K == self.K - 1:
+            e = self._epoch()
+            i = e % len(self._done)
             stream = stream or torch.cuda.current_stream(self.device)
-            side = self._sides[e % 2]
-            ev = self._launched[e % 4]
-            ev.record(stream)
-            side.wait_event(ev)
-            nat.check(self._lib.rbg_stash_refill_gen(self._g, self.B, self.m, self.N,
-                                                     C.byref(self.struct),
-                                                     C.c_void_p(side.cuda_stream)),
-                      "rbg_stash_refill")
-            self._done[e % 4].record(side)
+            self._launched[i].record(stream)
+            gs = self._gen_streams[e % len(self._gen_streams)]
+            gs.wait_event(self._launched[i])
+            if e > 0:  # list launches in order: each sees the claims of the one before
+                gs.wait_event(self._listed[(e - 1) % len(self._listed)])
+            nat.check(self._lib.rbg_stash_list(self.B, self.m, self.N, C.byref(self._structs[i]),
+                                               C.c_void_p(gs.cuda_stream)), "rbg_stash_list")
+            self._listed[i].record(gs)
+            nat.check(self._lib.rbg_stash_refill_listed(self._g, self.B, self.m, self.N,
+                                                        C.byref(self._structs[i]),
+                                                        C.c_void_p(gs.cuda_stream)),
+                      "rbg_stash_refill_listed")
+            self._done[i].record(gs)
         self.sched.launched()
 
     def drain(self, stream: Optional[torch.cuda.Stream] = None) -> None:
@@ -703,7 +777,7 @@ class EpochStash:
         if self.serial:
             return
         stream = stream or torch.cuda.current_stream(self.device)
-        for side in self._sides:
+        for side in self._gen_streams:
             stream.wait_stream(side)
 
 
@@ -723,7 +797,8 @@ class StepLoop:
                  connected_reward: float = 0.1, refill_every: int = 0,
                  fuse_policy: bool = False, auto_reset: bool = True,
                  serial_refill: bool = True, stash_depth: int = 1,
-                 gen: Optional[GeneratorSpec] = None) -> None:
+                 gen: Optional[GeneratorSpec] = None, refill_lead: int = 2,
+                 refill_streams: int = 2) -> None:
         B, m, _ = state["grid"].shape
         N = state["start"].shape[1]
         dev = state["grid"].device
@@ -742,7 +817,8 @@ class StepLoop:
         self.fuse_policy = bool(fuse_policy)  # policy + step in ONE launch (rollout of 1 step)
         self.gen, self._g = gen, _gen_ref(gen)
         self._epochs = (EpochStash(B, m, N, dev, self.K, serial=serial_refill, depth=stash_depth,
-                                   gen=gen) if self.K else None)
+                                   gen=gen, lead=refill_lead, streams=refill_streams)
+                        if self.K else None)
         self._hp = None
         if self.K:
             self.stash, self._h = self._epochs.stash, self._epochs.struct
@@ -1054,7 +1130,7 @@ class ConnectorSession:
         if self.K:
             if self.epochs is not None:
                 self.epochs.drain()
-            kw = ({k: v for k, v in self.gen.refill.items() if k in ("depth", "serial", "adaptive")}
+            kw = ({k: v for k, v in self.gen.refill.items() if k in ("depth", "serial", "adaptive", "lead", "streams")}
                   if self.gen is not None else {})
             ep = self.epochs = EpochStash(self.B, self.m, self.N, self.device, self.K,
                                           gen=self.gen, **kw)

@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--agents", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--configs", default="0:1:1,16:1:1,16:1:2,48:1:2,16:0:1,16:0:2,32:0:2,48:0:2",
-                    help="K:serial:depth triples; K = 0 is the inline (fused) reset")
+                    help="K:serial:depth[:lead[:streams]]; K = 0 is the inline (fused) reset; serial = 0: "
+                         "rolling refills beside the stepping stream")
     ap.add_argument("--flags", default="", help="extra hipcc flags: time a variant build of the "
                                                 "library (built here, into gpurun_out/)")
     args = ap.parse_args()
@@ -58,10 +59,11 @@ def main():
                 n_last += (ts["step_type"] == 2).sum()
         episodes = int(n_last.item())
         for cfg in args.configs.split(","):
-            K, serial, depth = (int(x) for x in cfg.split(":"))
+            K, serial, depth, lead, streams = ([int(x) for x in cfg.split(":")] + [2, 2])[:5]
             st, ts = ops.alloc_state(B, m, N, dev), ops.alloc_timestep(B, m, N, dev)
             loop = ops.StepLoop(st, ts, keys, refill_every=K, fuse_policy=True, gen=gen,
-                                serial_refill=bool(serial), stash_depth=depth)
+                                serial_refill=bool(serial), stash_depth=depth, refill_lead=lead,
+                                refill_streams=streams)
             loop.reset(keys)
             for t in range(60):
                 loop.step(t)
@@ -69,6 +71,7 @@ def main():
             torch.cuda.synchronize(dev)
             if K:
                 loop.stash["hits"].zero_()
+                loop.stash["misses"].zero_()
             t0 = time.perf_counter()
             e0.record()
             for t in range(60, 60 + args.steps):
@@ -79,7 +82,9 @@ def main():
             loop.drain()
             us = e0.elapsed_time(e1) / args.steps * 1e3
             hits = int(loop.stash["hits"].sum().item()) if K else 0
+            misses = int(loop.stash["misses"].sum().item()) if K else 0
             rows.append({"generator": name, "K": K, "serial": serial, "depth": depth,
+                         **({} if serial else {"lead": lead, "streams": streams}), "misses": misses,
                          "us_per_step": round(us, 2), "wall_us_per_step": round(wall / args.steps * 1e6, 2),
                          "env_steps_per_s": round(B / us * 1e6 / 1e6, 1),
                          "episodes": episodes, "stash_hits": hits})
