@@ -371,8 +371,9 @@ def env_steps_by_generator(keys, m, N, steps, close=None):
                             stash_depth=sched["depth"], serial_refill=sched["serial"],
                             refill_lead=sched["lead"], refill_streams=sched["streams"])
         loop.reset(keys)
-        # (rolling refills: the pipeline of refills in flight is full after lead + 1 epochs)
-        warm = max(60, (2 if sched["serial"] else sched["lead"] + 2) * sched["every"])
+        # (rolling refills: the reset's own refill generates depth x B boards, and the pipeline of
+        # refills in flight is full after lead + 1 epochs)
+        warm = max(60, (2 if sched["serial"] else sched["lead"] + 3) * sched["every"])
         for t in range(warm):
             loop.step(t)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -224,7 +224,7 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  * the envs that restarted recently (a throughput-shaped batch of walks) instead of by every step
  * launch for its own few finished envs (a launch that lasts as long as its longest walk); the
  * step then copies 1.3 KB instead of walking.
- *   depth       slots per env, 1 .. 8; slot s of env b is row s * B + b of every array below
+ *   depth       slots per env, 1 .. 12; slot s of env b is row s * B + b of every array below
  *   next        a full rbg_state of depth * B rows: next[r] = reset(split(tag[r])[0])
  *   tag         uint32 [depth*B][2]: the State.key next[r] was generated for (zero-initialised)
  *   ready_at    int32 [depth*B]: first launch tick that may consume the row (zero-initialised)

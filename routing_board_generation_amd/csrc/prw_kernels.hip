@@ -565,7 +565,7 @@ static int stash_refill_impl(const rbg_generator *generator, int B, int m, int N
   a.B = B * stash->depth;  // the kernel works on rows
   a.N = N;
   const int envs_per_block = wpb * (kWaveSize / lpb);
-  const dim3 grid((a.B + envs_per_block - 1) / envs_per_block), block(kWaveSize * wpb);
+  dim3 grid((a.B + envs_per_block - 1) / envs_per_block), block(kWaveSize * wpb);
   hipStream_t st = (hipStream_t)stream;
   const bool list_here = mode == 1 || (mode == 0 && kind == kGenSeedExt && a.stash.scratch &&
                                        lpb < kWaveSize);
@@ -578,6 +578,8 @@ static int stash_refill_impl(const rbg_generator *generator, int B, int m, int N
     if (mode == 1) return check_hip(hipGetLastError(), "rbg_stash_list");
   }
   a.listed = (list_here || mode == 2) ? 1 : 0;
+  // a listed launch strides over its list: four workgroups per CU at most (see the kernel)
+  if (a.listed && grid.x > 4u * 256u) grid.x = 4u * 256u;
   if (kind == kGenUniform) {
     hipLaunchKernelGGL((stash_refill_gen_kernel<64, kGenUniform>), grid, block, lds, st, a);
   } else if (kind == kGenSeqRw) {
@@ -732,6 +734,8 @@ int rbg_connector_rollout_gen(const rbg_generator *generator, int B, int m, int 
   if (stash)
     if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_connector_rollout_prefetch")) return rc;
+  if (stash && stash->depth > kRolloutStashDepth)
+    return fail(RBG_E_PARAM, "rbg_connector_rollout: at most 2 stash slots per env in a rollout launch");
   a.tick = tick; a.ready_delay = ready_delay;
   const bool wants_stats = stats && (stats->episodes || stats->connections_made ||
                                      stats->unconnected_agent_steps || stats->final_connections ||

@@ -258,41 +258,52 @@ __global__ __launch_bounds__(kBlock) void stash_refill_gen_kernel(RefillArgs a) 
   const SubWave<LPB> sw(threadIdx.x & (kWaveSize - 1));
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = (int)(blockDim.x >> 6);
-  const int slot = (blockIdx.x * wpb + wib) * kSubs + sw.h;
-  uint2 want = make_uint2(0u, 0u);
-  bool need = false;
-  int b = slot;
-  if (a.listed) {  // slot i generates the i-th listed row
-    need = slot < a.stash.scratch[0];
-    b = need ? a.stash.scratch[1 + slot] : 0;
-    if (need) want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
-  } else if (b < a.B) {
-    want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
-    const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
-    need = want.x != have.x || want.y != have.y;
-  }
-  const uint64_t busy = __ballot(need);
-  if (busy == 0ull) return;  // wave-uniform
-  const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)busy) - 1);
-  Key2 key;
-  key.a = need ? want.x : (uint32_t)__builtin_amdgcn_readlane((int)want.x, src);
-  key.b = need ? want.y : (uint32_t)__builtin_amdgcn_readlane((int)want.y, src);
   const Geo g = a.g;
   uint32_t *board = g_lds + (wib * kSubs + sw.h) * env_slab_words<LPB>(g, a.gen);
   uint32_t *W = board + board_words(g);
-  AgentRegs ag = {0, 0, 0, 0, 0, 0};
-  Key2 rk, unused;
-  split2_lanes(sw, key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
-  const Key2 next_key = regenerate_kind<LPB, KIND>(sw, board, W, g, a.N, rk, ag, a.gen);
-  if (need) {
-    store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
-    if (sw.l == 0) {
-      *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
-      if (a.listed && a.stash.inflight) {
-        __threadfence();  // whoever sees the row released also sees its tag
-        a.stash.inflight[b] = 0;
+  // A listed launch comes with a grid smaller than the row count (the host does not know how many
+  // rows are listed, and thousands of workgroups that start only to find nothing to do cost the
+  // dispatcher ~30 ns each -- 0.1-0.2 ms per refill at 8-12 slots per env, during which the step
+  // launches of the other queue starve): its workgroups stride over the list.
+  for (int blk = blockIdx.x;; blk += gridDim.x) {
+    const int slot = (blk * wpb + wib) * kSubs + sw.h;
+    uint2 want = make_uint2(0u, 0u);
+    bool need = false;
+    int b = slot;
+    if (a.listed) {  // slot i generates the i-th listed row
+      const int count = a.stash.scratch[0];
+      if (blk * wpb * kSubs >= count) return;  // (uniform in the workgroup)
+      need = slot < count;
+      b = need ? a.stash.scratch[1 + slot] : 0;
+      if (need) want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
+    } else if (b < a.B) {
+      want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)b]);
+      const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)b]);
+      need = want.x != have.x || want.y != have.y;
+    }
+    const uint64_t busy = __ballot(need);
+    if (busy != 0ull) {  // wave-uniform
+      const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)busy) - 1);
+      Key2 key;
+      key.a = need ? want.x : (uint32_t)__builtin_amdgcn_readlane((int)want.x, src);
+      key.b = need ? want.y : (uint32_t)__builtin_amdgcn_readlane((int)want.y, src);
+      AgentRegs ag = {0, 0, 0, 0, 0, 0};
+      Key2 rk, unused;
+      split2_lanes(sw, key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
+      const Key2 next_key = regenerate_kind<LPB, KIND>(sw, board, W, g, a.N, rk, ag, a.gen);
+      if (need) {
+        store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
+        if (sw.l == 0) {
+          *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
+          if (a.listed && a.stash.inflight) {
+            __threadfence();  // whoever sees the row released also sees its tag
+            a.stash.inflight[b] = 0;
+          }
+        }
       }
     }
+    if (!a.listed) return;  // a scan: one slot per sub-wave
+    wave_lds_fence();
   }
 }
 

@@ -69,6 +69,10 @@ __device__ __forceinline__ Key2 uni(Key2 k) {
 // per env at 16x16/10, which makes it an HBM stream instead of an LDS-resident loop.
 // (a recording full-wave env needs a few registers more than the 128 of four waves per SIMD
 // leave; it is HBM-bound, so three waves per SIMD cost it nothing)
+// slots per env a rollout launch handles (two is what a many-step launch needs; the request rule
+// is unrolled over them, and the full-wave rollout kernel has no registers to spare)
+constexpr int kRolloutStashDepth = 2;
+
 template <int LPB, bool kRecord, int KIND>
 __device__ __forceinline__ void rollout_body(const RolloutArgs &a) {
   constexpr int kSubs = SubWave<LPB>::kSubs;
@@ -143,7 +147,7 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a) {
         }
         step_count = 0;
         key = uni<LPB>(key);
-        request_refill<KIND>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+        request_refill<KIND, kRolloutStashDepth>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
         bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
       }
     }

@@ -20,7 +20,7 @@ struct StashPtrs {
   uint32_t *far_key;     // [B][2] nullable: the farthest key env b has requested a row for
   int depth;             // 1 .. kMaxStashDepth
 };
-constexpr int kMaxStashDepth = 8;
+constexpr int kMaxStashDepth = 12;
 
 // Row of the stash that holds the successor of the episode with State.key `key`, or -1.
 __device__ __forceinline__ int stash_lookup(const StashPtrs &st, int B, int b, Key2 key,
@@ -126,7 +126,7 @@ __device__ __forceinline__ void stash_row_commit(const SubWave<64> &sw, uint32_t
 // consumed row takes the one new request, f(far), and far moves on -- two Threefry evaluations
 // and two stores instead of up to 2 (D - 1) evaluations and D^2 compares on the wave the launch
 // is waiting for.  `far_in` = the env's far key as fetched with the early probe (lane 0).
-template <int KIND, int LPB>
+template <int KIND, int MAXD = 12, int LPB>
 __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const StashPtrs &st, int B,
                                                int b, Key2 key, int ready_at, int hit_row = -1,
                                                bool have_far = false,
@@ -157,25 +157,25 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
     }
     return;
   }
-  const int D = st.depth < kMaxStashDepth ? st.depth : kMaxStashDepth;
-  Key2 want[kMaxStashDepth];
+  const int D = st.depth < MAXD ? st.depth : MAXD;  // (MAXD: what this kernel is built for)
+  Key2 want[MAXD];
   want[0] = key;
 #pragma unroll
-  for (int j = 1; j < kMaxStashDepth; ++j) {
+  for (int j = 1; j < MAXD; ++j) {
     want[j] = want[j - 1];
     if (j < D) want[j] = next_state_key<LPB, KIND>(sw, want[j - 1]);  // (uniform branch)
   }
   if (sw.l == 0) {
-    uint2 cur[kMaxStashDepth];
+    uint2 cur[MAXD];
     uint32_t row_used = 0u, want_met = 0u;
 #pragma unroll
-    for (int s = 0; s < kMaxStashDepth; ++s)
+    for (int s = 0; s < MAXD; ++s)
       cur[s] = s < D ? *reinterpret_cast<const uint2 *>(&st.refill_key[2 * ((size_t)s * B + b)])
                      : make_uint2(0u, 0u);
 #pragma unroll
-    for (int j = 0; j < kMaxStashDepth; ++j) {
+    for (int j = 0; j < MAXD; ++j) {
 #pragma unroll
-      for (int s = 0; s < kMaxStashDepth; ++s) {
+      for (int s = 0; s < MAXD; ++s) {
         const bool hit = j < D && s < D && !((row_used >> s) & 1u) && !((want_met >> j) & 1u) &&
                          cur[s].x == want[j].a && cur[s].y == want[j].b;
         row_used |= (uint32_t)hit << s;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
       }
     }
 #pragma unroll
-    for (int j = 0; j < kMaxStashDepth; ++j) {
+    for (int j = 0; j < MAXD; ++j) {
       if (j < D && !((want_met >> j) & 1u)) {
         const int s = __builtin_ctz(~row_used);  // a free row exists: D rows, fewer than D kept
         const size_t r = (size_t)s * B + b;
@@ -195,7 +195,7 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
     if (st.far_key) {
       Key2 far = want[0];
 #pragma unroll
-      for (int j = 1; j < kMaxStashDepth; ++j) far = j < D ? want[j] : far;
+      for (int j = 1; j < MAXD; ++j) far = j < D ? want[j] : far;
       *reinterpret_cast<uint2 *>(&st.far_key[2 * (size_t)b]) = make_uint2(far.a, far.b);
     }
   }

@@ -30,14 +30,14 @@ class SeedExtensionGenerator(Generator):
         from .. import _native as nat
 
         # random_seed_generator.py:36-37: generate_starts_ends(key) with its defaults
-        # (refill: a launch of 1.4-2 ms whatever its row count -- rolling refills beside the
-        # stepping stream, three in flight, every entry requested seven episodes ahead: 18-28 us
-        # per step depending on how the refills happen to overlap, against 42-47 in line;
+        # (refill: a launch of 1.4-2.2 ms whatever its row count -- rolling refills beside the
+        # stepping stream, two in flight on two generator streams, every entry requested nine
+        # episodes ahead: 18.2 us per step against 42-47 with one refill per 48 steps in line;
         # DESIGN.md 4.2a)
         return ops.GeneratorSpec(nat.GEN_SEED_EXTENSION, randomness=0.0, two_sided=True,
                                  extension_iterations=1, max_extension_steps=ops.INT32_MAX,
-                                 refill={"every": 56, "depth": 8, "serial": False, "lead": 3,
-                                         "streams": 3, "record_stash": True})
+                                 refill={"every": 64, "depth": 10, "serial": False, "lead": 3,
+                                         "streams": 2, "record_stash": True})
 
 
 RandomSeedGenerator = SeedExtensionGenerator

@@ -29,9 +29,10 @@ class SequentialRandomWalkGenerator(Generator):
 
         # a refill launch lasts as long as its slowest board (~0.4 ms at 16x16/10) however few rows
         # it generates, and leaves most of the chip idle: rolling refills beside the stepping
-        # stream (ops.EpochStash(serial=False)), every entry requested five episodes ahead; on
-        # misses (short episodes) the stash falls back to the serial, miss-adaptive form
-        # (17.9 against 22.8 us per step for one refill per 48 steps in line)
+        # stream (ops.EpochStash(serial=False)), one generator stream, every entry requested
+        # seven episodes ahead; on misses (short episodes) the stash falls back to the serial,
+        # miss-adaptive form (17.9 us per step against 22.5 for one refill per
+        # 48 steps in line)
         return ops.GeneratorSpec(nat.GEN_SEQUENTIAL_RW,
-                                 refill={"every": 16, "depth": 6, "serial": False, "lead": 3,
-                                         "streams": 2, "rollout_stash": False})
+                                 refill={"every": 32, "depth": 8, "serial": False, "lead": 3,
+                                         "streams": 1, "rollout_stash": False})

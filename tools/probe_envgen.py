@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--configs", default="0:1:1,16:1:1,16:1:2,48:1:2,16:0:1,16:0:2,32:0:2,48:0:2",
                     help="K:serial:depth[:lead[:streams]]; K = 0 is the inline (fused) reset; serial = 0: "
                          "rolling refills beside the stepping stream")
+    ap.add_argument("--warm", type=int, default=60, help="untimed steps before the timed window")
+    ap.add_argument("--chunks", type=int, default=1, help="time the window in this many pieces")
     ap.add_argument("--flags", default="", help="extra hipcc flags: time a variant build of the "
                                                 "library (built here, into gpurun_out/)")
     args = ap.parse_args()
@@ -53,9 +55,9 @@ def main():
         loop = ops.StepLoop(st, ts, keys, refill_every=0, fuse_policy=True, gen=gen)
         loop.reset(keys)
         n_last = torch.zeros((), dtype=torch.int64, device=dev)
-        for t in range(60 + args.steps):
+        for t in range(args.warm + args.steps):
             loop.step(t)
-            if t >= 60:
+            if t >= args.warm:
                 n_last += (ts["step_type"] == 2).sum()
         episodes = int(n_last.item())
         for cfg in args.configs.split(","):
@@ -65,17 +67,22 @@ def main():
                                 serial_refill=bool(serial), stash_depth=depth, refill_lead=lead,
                                 refill_streams=streams)
             loop.reset(keys)
-            for t in range(60):
+            for t in range(args.warm):
                 loop.step(t)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.chunks + 1)]
             torch.cuda.synchronize(dev)
             if K:
                 loop.stash["hits"].zero_()
                 loop.stash["misses"].zero_()
             t0 = time.perf_counter()
             e0.record()
-            for t in range(60, 60 + args.steps):
+            marks[0].record()
+            per = max(1, args.steps // args.chunks)
+            for t in range(args.warm, args.warm + args.steps):
                 loop.step(t)
+                if (t - args.warm + 1) % per == 0 and (t - args.warm + 1) // per <= args.chunks:
+                    marks[(t - args.warm + 1) // per].record()
             e1.record()
             torch.cuda.synchronize(dev)
             wall = time.perf_counter() - t0
@@ -87,7 +94,10 @@ def main():
                          **({} if serial else {"lead": lead, "streams": streams}), "misses": misses,
                          "us_per_step": round(us, 2), "wall_us_per_step": round(wall / args.steps * 1e6, 2),
                          "env_steps_per_s": round(B / us * 1e6 / 1e6, 1),
-                         "episodes": episodes, "stash_hits": hits})
+                         "episodes": episodes, "stash_hits": hits,
+                         **({"chunks_us_per_step": [round(a.elapsed_time(b) / per * 1e3, 1)
+                                                    for a, b in zip(marks, marks[1:])]}
+                            if args.chunks > 1 else {})})
             print(json.dumps(rows[-1]), flush=True)
             torch.cuda.synchronize(dev)
 
