@@ -937,7 +937,9 @@ class GroupedStepLoop:
             hi = lo + base + (1 if g < extra else 0)
             self.bounds.append((lo, hi))
             lo = hi
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.groups)]
+        # (from the process's pool of side streams -- see generator_streams -- as far as it goes)
+        pool = generator_streams(dev, self.groups)
+        self.streams = pool + [torch.cuda.Stream(device=dev) for _ in range(self.groups - len(pool))]
         self.loops = []
         cur = torch.cuda.current_stream(dev)
         for (lo, hi), st in zip(self.bounds, self.streams):
