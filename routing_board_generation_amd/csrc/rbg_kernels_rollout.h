@@ -71,7 +71,10 @@ __device__ __forceinline__ Key2 uni(Key2 k) {
 // leave; it is HBM-bound, so three waves per SIMD cost it nothing)
 // slots per env a rollout launch handles (two is what a many-step launch needs; the request rule
 // is unrolled over them, and the full-wave rollout kernel has no registers to spare)
-constexpr int kRolloutStashDepth = 2;
+#ifndef RBG_ROLLOUT_STASH_DEPTH
+#define RBG_ROLLOUT_STASH_DEPTH 2
+#endif
+constexpr int kRolloutStashDepth = RBG_ROLLOUT_STASH_DEPTH;
 
 template <int LPB, bool kRecord, int KIND>
 __device__ __forceinline__ void rollout_body(const RolloutArgs &a) {
@@ -147,7 +150,8 @@ __device__ __forceinline__ void rollout_body(const RolloutArgs &a) {
         }
         step_count = 0;
         key = uni<LPB>(key);
-        request_refill<KIND, kRolloutStashDepth>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+        request_refill<KIND, kRolloutStashDepth>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay,
+                                                 row);
         bits = is_agent ? action_mask_bits(board, g, ag, l) : 1u;
       }
     }

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _native as nat
-from .schedule import RefillSchedule
+from .schedule import MissWatch, RefillSchedule
 
 StateBufs = Dict[str, torch.Tensor]
 TimestepBufs = Dict[str, torch.Tensor]
@@ -665,12 +665,12 @@ class EpochStash:
             self._miss_dev = torch.zeros((1,), dtype=torch.int64, device=device)
             self._miss_host = torch.zeros((1,), dtype=torch.int64).pin_memory()
         self.fell_back = False
+        self._watch, self._refills = MissWatch(), 0
         if not self.serial:
             # a stash that misses in rolling form (episodes much shorter than the lead it was
             # sized for) falls back to the serial, miss-adaptive form for good: _watch_misses
             self._miss_dev = torch.zeros((1,), dtype=torch.int64, device=device)
             self._miss_host = torch.zeros((1,), dtype=torch.int64).pin_memory()
-            self._miss_seen = 0
             self.lead = max(2, int(lead))
             ring = self.lead + 1
             # (no stream of its own for the listing: HIP multiplexes streams onto 4 hardware
@@ -723,21 +723,31 @@ class EpochStash:
             (stream or torch.cuda.current_stream(self.device)).wait_event(
                 self._done[(e - self.lead) % len(self._done)])
 
-    def _adapt(self, stream: Optional[torch.cuda.Stream]) -> None:
-        """Halve the period while misses keep coming, let it grow back after four calm refills."""
-        self.sched.observe_misses(int(self._miss_host[0]))  # whatever has arrived (no sync)
+    def _send_misses(self, stream: Optional[torch.cuda.Stream], stamp: int) -> None:
+        """Queue a snapshot of the stash's miss counter, stamped, to pinned host memory (no
+        synchronisation; schedule.MissWatch decodes it whenever it has arrived)."""
         with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
             torch.sum(self.stash["misses"], dim=0, keepdim=True, out=self._miss_dev)
+            self._miss_dev.mul_(1 << MissWatch.STAMP_BITS).add_(stamp & MissWatch.STAMP_MASK)
             self._miss_host.copy_(self._miss_dev, non_blocking=True)
+
+    def _adapt(self, stream: Optional[torch.cuda.Stream]) -> None:
+        """Halve the period while misses keep coming, let it grow back after four calm refills."""
+        got = self._watch.observe(int(self._miss_host[0]))  # whatever has arrived (no sync)
+        if got is not None:
+            self.sched.observe_misses(*got)
+        self._refills += 1
+        self._send_misses(stream, self._refills)
 
     def _watch_misses(self, stream: torch.cuda.Stream) -> None:
         """Rolling form, once per epoch: the stash's miss counter travels to pinned host memory
-        without synchronising; if it grew by more than batch / 64 since the last look the lead
-        time this stash was sized for does not hold (short episodes: a trained policy), and every
-        miss stalls a step launch for a board's latency -- so the stepping stream waits for the
-        refills in flight once and the stash carries on in the serial, miss-adaptive form."""
-        seen = int(self._miss_host[0])
-        if seen - self._miss_seen > max(1, self.B // 64):
+        without synchronising; if it grew by more than batch / 64 per epoch since the last
+        snapshot the lead time this stash was sized for does not hold (short episodes: a trained
+        policy), and every miss stalls a step launch for a board's latency -- so the stepping
+        stream waits for the refills in flight once and the stash carries on in the serial,
+        miss-adaptive form."""
+        got = self._watch.observe(int(self._miss_host[0]))
+        if got is not None and got[0] > max(1, self.B // 64) * got[1]:
             self.drain(stream)
             with torch.cuda.stream(stream):
                 # every producer has finished: a row is consistent with its tag, so rows asked for
@@ -747,11 +757,9 @@ class EpochStash:
             self.sched.adaptive = self.adaptive = True
             self.sched.K = self.sched.K0 = min(self.sched.K0, 48)
             self.sched.refill_after = self.sched.tick  # a refill right behind this launch
+            self._refills = self._epoch() + 1  # (the serial form's stamps carry on from the last epoch's)
             return
-        self._miss_seen = seen
-        with torch.cuda.stream(stream):
-            torch.sum(self.stash["misses"], dim=0, keepdim=True, out=self._miss_dev)
-            self._miss_host.copy_(self._miss_dev, non_blocking=True)
+        self._send_misses(stream, self._epoch() + 1)
 
     def after_launch(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Right after it: the last launch of an epoch queues the refill."""

@@ -3,19 +3,22 @@ when refills are queued, which tick a request becomes usable at, how the adaptiv
 The device side (rows, tags, requests) is covered by the GPU tests against the oracle."""
 import random
 
-from routing_board_generation_amd.schedule import RefillSchedule
+from routing_board_generation_amd.schedule import MissWatch, RefillSchedule
 
 
 def drive(sched, launches, misses_at=None):
     """Run `launches` ticks; returns (ready tick announced by every launch, ticks followed by a
     refill).  misses_at: tick -> cumulative miss count the host sees at the refill behind it."""
     announced, refills = [], []
+    seen = getattr(sched, "_test_seen", 0)
     for _ in range(launches):
         announced.append(sched.tick + sched.ready_delay())
         if sched.refill_due():
             refills.append(sched.tick)
             if misses_at is not None:
-                sched.observe_misses(misses_at(sched.tick))
+                now = misses_at(sched.tick)
+                sched.observe_misses(now - seen)
+                seen = sched._test_seen = now
             sched.refill_queued()
         sched.launched()
     return announced, refills
@@ -78,4 +81,36 @@ def test_a_few_misses_do_not_move_the_period():
         return total[0]
 
     drive(s, 500, drizzle)
+    assert s.K == 32
+
+
+def test_miss_snapshots_are_counted_once_per_stamp():
+    """A host that runs ahead of the device reads the same snapshot many times, then several
+    refills' worth at once: increments are handed out per stamp, stale reads give nothing."""
+    w = MissWatch()
+    assert w.observe(0) is None                                 # nothing has arrived yet
+    assert w.observe(MissWatch.pack(10, 1)) == (10, 1)
+    assert w.observe(MissWatch.pack(10, 1)) is None             # the same snapshot again
+    assert w.observe(MissWatch.pack(130, 7)) == (120, 6)        # six refills later: 20 per refill
+    top = MissWatch.STAMP_MASK
+    w.stamp, w.misses = top, 130
+    assert w.observe(MissWatch.pack(131, top + 2)) == (1, 2)    # the stamp wraps
+
+
+def test_a_lagging_counter_is_neither_a_storm_nor_calm():
+    """12 misses per refill (below batch / 64 = 64) arriving as one snapshot per 40 refills: the
+    period stays; the same lag with 100 per refill halves it; stale reads never count as calm."""
+    s = RefillSchedule(every=32, batch=4096, adaptive=True)
+    w = MissWatch()
+    for snap in range(1, 6):
+        for _ in range(39):
+            assert w.observe(MissWatch.pack(12 * 40 * (snap - 1), 40 * (snap - 1))) is None
+        s.observe_misses(*w.observe(MissWatch.pack(12 * 40 * snap, 40 * snap)))
+    assert s.K == 32
+    s.observe_misses(*w.observe(MissWatch.pack(12 * 200 + 100 * 40, 240)))
+    assert s.K == 16
+    for _ in range(100):                                         # nothing new arrives: K stays put
+        assert w.observe(MissWatch.pack(12 * 200 + 100 * 40, 240)) is None
+    assert s.K == 16
+    s.observe_misses(*w.observe(MissWatch.pack(12 * 200 + 100 * 40, 244)))  # four calm refills
     assert s.K == 32
