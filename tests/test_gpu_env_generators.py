@@ -270,7 +270,9 @@ def test_adaptive_refill_period_follows_short_episodes(rbg, oracle):
         assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
         periods.append(sess.epochs.K)
     assert sess.epochs.fell_back and sess.epochs.serial and sess.epochs.adaptive
-    assert min(periods) <= 8, periods[::20]
+    # (eight slots per env cover 32 steps of 4-step episodes: the period halves until the misses
+    # per refill stop, which they do at 16)
+    assert min(periods) <= 16, periods[::20]
     misses = int(to_np(sess.epochs.stash["misses"]).sum())
     hits = int(to_np(sess.epochs.stash["hits"]).sum())
     assert misses > 0 and hits > misses, (hits, misses)
