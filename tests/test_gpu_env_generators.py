@@ -438,19 +438,22 @@ def test_stash_request_rule_under_hits_and_misses(rbg, oracle, depth, delay, tl)
     sess.drain()
 
 
+@pytest.mark.parametrize("B,steps", [(192, 1500), (4096, 700)])
 @pytest.mark.parametrize("name", ["online_parallel_rw", "online_seq_rw", "online_random_seed",
                                   "offline_seed_extension"])
-def test_long_runs_do_not_depend_on_the_stash_schedule(rbg, name):
+def test_long_runs_do_not_depend_on_the_stash_schedule(rbg, name, B, steps):
     """1500 auto-resetting steps (about 40 episodes per env) through the drop-in classes, once
     with every restart running the generator inline and once with the generator's default
     next-episode-stash schedule (output chunks reused, adaptive period): the same final State,
-    the same reward total, the same number of episodes."""
+    the same reward total, the same number of episodes.  The B = 4096 rows are the benchmark's
+    batch: the refills that roll beside the stepping stream (SequentialRandomWalk, SeedExtension)
+    then really overlap hundreds of step launches, and no host synchronisation paces them."""
     import torch
 
     from routing_board_generation_amd import ops
     from routing_board_generation_amd.interface.board_generator_interface import make_online_generator
 
-    m, N, B, steps = 16, 10, 192, 1500
+    m, N = 16, 10
     keys, akeys = _keys(rbg, 61, B), _keys(rbg, 62, B)
     results = []
     for prefetch in (False, True):
@@ -469,6 +472,12 @@ def test_long_runs_do_not_depend_on_the_stash_schedule(rbg, name):
         results.append((state_to_np(state), to_np(total), int(episodes)))
         for sess in env.unwrapped._sessions.values():
             sess.drain()
+            ep = sess.epochs
+            if prefetch and B == 4096 and name in ("online_seq_rw", "online_random_seed"):
+                # the rolling form held (no fallback to in-line refills) and served the resets
+                assert ep is not None and not ep.serial and not ep.fell_back
+                hits, misses = int(to_np(ep.stash["hits"]).sum()), int(to_np(ep.stash["misses"]).sum())
+                assert hits > 0.98 * int(episodes) and misses < 0.02 * int(episodes), (hits, misses)
     assert_dicts_equal(results[0][0], results[1][0], f"{name} final state.")
     assert (results[0][1] == results[1][1]).all() and results[0][2] == results[1][2]
-    assert results[0][2] > 25 * B
+    assert results[0][2] > (steps // 60) * B
