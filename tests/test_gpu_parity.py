@@ -999,6 +999,43 @@ def test_many_boards_match_oracle(rbg, oracle, torch_mod, m, N, log2b):
         assert (to_np(out["key_out"]) == st["key"]).all()
 
 
+def test_batches_beyond_two_gib_per_field(rbg, torch_mod):
+    """Sized for 288 GB: 3 M boards in ONE generator launch (2.9 GiB per grid field) and 300 k
+    envs in one reset / step launch (2.9 GiB of observation) -- every offset past 2^31 bytes.
+    Boards are independent, so slices of the big launch must equal small launches of the same
+    keys (shard invariance at a size the oracle is not needed for)."""
+    from routing_board_generation_amd import ops
+
+    B = 3_000_000
+    keys = rbg.split(rbg.PRNGKey(7), B)
+    kw = dict(split_first=True, want_solved=True, want_train=True, want_state=True, want_iters=True)
+    out = ops.prw_generate(keys, 16, 10, **kw)
+    for lo in (0, 1_500_000, 2_097_152 - 500, B - 1000):
+        sub = ops.prw_generate(keys[lo:lo + 1000].contiguous(), 16, 10, **kw)
+        for k in ("solved_grid", "train_grid", "start", "target", "key_out", "iters"):
+            assert bool((out[k][lo:lo + 1000] == sub[k]).all()), (lo, k)
+    del out
+    B2, tail = 300_000, 512
+    k2 = keys[:B2].contiguous()
+    results = []
+    for kk in (k2, k2[B2 - tail:].contiguous()):
+        env = rbg.VmapAutoResetWrapper(rbg.Connector(rbg.ParallelRandomWalkGenerator(16, 10),
+                                                     time_limit=2))
+        policy = ops.RandomPolicy(kk, 10)
+        state, ts = env.reset(kk)
+        for t in range(3):  # (time_limit 2: the last step restarts every env from its stash row)
+            state, ts = env.step(state, policy(t, ts.observation.action_mask))
+        results.append((state, ts))
+        for sess in env.unwrapped._sessions.values():
+            sess.drain()
+    (sb, tb), (ss, tsm) = results
+    assert tb.observation.grid.numel() * 4 > 2 ** 31
+    assert bool((sb.grid[B2 - tail:] == ss.grid).all()) and bool((sb.key[B2 - tail:] == ss.key).all())
+    assert bool((tb.observation.grid[B2 - tail:] == tsm.observation.grid).all())
+    assert bool((tb.reward[B2 - tail:] == tsm.reward).all())
+    assert bool((tb.observation.action_mask[B2 - tail:] == tsm.observation.action_mask).all())
+
+
 def test_random_agent_loop_example_runs():
     """examples/random_agent_loop.py: the reference's acting loop on the drop-in classes."""
     import os
