@@ -81,6 +81,59 @@ def test_argument_errors_do_not_need_a_gpu(native):
         native.check(-2, "rbg_prw_generate")
 
 
+def test_argument_errors_of_the_generator_and_stash_entry_points(native):
+    """The ABI 8 entry points (rbg_generator, rbg_step_call, rolling refills) check their
+    arguments before any launch: no GPU needed, nothing is dereferenced on the device."""
+    nat = native
+    lib = nat.lib()
+    one = 16  # stands for a device pointer; never dereferenced by the checks
+    assert lib.rbg_connector_step_call(None) == -1 and b"NULL call" in lib.rbg_last_error()
+    call = nat.StepCall()
+    call.B, call.m, call.N = 1, 16, 10
+    call.params = nat.EnvParams(0, -0.03, 0.1, 1)
+    assert lib.rbg_connector_step_call(C.byref(call)) == -3 and b"time_limit" in lib.rbg_last_error()
+    call.params = nat.EnvParams(50, -0.03, 0.1, 1)
+    call.m = 41
+    assert lib.rbg_connector_step_call(C.byref(call)) == -2
+    call.m = 16
+    assert lib.rbg_connector_step_call(C.byref(call)) == -1  # incomplete state
+    # generator descriptors
+    state = nat.State(*[one] * 6)
+    stash = nat.Stash(state, one, one, one, None, None, None, None, None, 1)
+    for gen, m, N, rc, msg in (
+            (nat.Generator(99, 0.0, 1, 1, 1, 0, None, None), 16, 10, -3, b"unknown generator kind"),
+            (nat.Generator(nat.GEN_UNIFORM, 0.0, 1, 1, 1, 0, None, None), 4, 9, -2, b"2N exceeds"),
+            (nat.Generator(nat.GEN_SEED_EXTENSION, 0.0, 1, 1, 1, 0, None, None), 4, 5, -2,
+             b"seed cells"),
+            (nat.Generator(nat.GEN_SEED_EXTENSION, 0.0, 1, -1, 1, 0, None, None), 16, 10, -3,
+             b"iteration"),
+            (nat.Generator(nat.GEN_DATASET, 0.0, 1, 1, 1, 0, one, one), 16, 10, -2, b"n_boards"),
+            (nat.Generator(nat.GEN_DATASET, 0.0, 1, 1, 1, 7, None, one), 16, 10, -1,
+             b"NULL boards")):
+        assert lib.rbg_stash_refill_gen(C.byref(gen), 8, m, N, C.byref(stash), None) == rc, msg
+        assert msg in lib.rbg_last_error(), lib.rbg_last_error()
+    seq = nat.Generator(nat.GEN_SEQUENTIAL_RW, 0.0, 1, 1, 1, 0, None, None)
+    assert lib.rbg_stash_refill_gen(C.byref(seq), 8, 2, 1, C.byref(stash), None) == -2  # m >= 3
+    # the stash itself
+    assert lib.rbg_stash_refill_gen(None, 8, 16, 10, None, None) == -1
+    deep = nat.Stash(state, one, one, one, None, None, None, None, None, 13)
+    assert lib.rbg_stash_refill_gen(None, 8, 16, 10, C.byref(deep), None) == -3
+    assert b"depth" in lib.rbg_last_error()
+    assert lib.rbg_stash_list(8, 16, 10, C.byref(stash), None) == -1          # no scratch area
+    assert lib.rbg_stash_refill_listed(None, 8, 16, 10, C.byref(stash), None) == -1
+    assert b"scratch" in lib.rbg_last_error()
+    # a rollout launch handles two slots per env
+    three = nat.Stash(state, one, one, one, None, None, None, None, None, 3)
+    params = nat.EnvParams(50, -0.03, 0.1, 1)
+    rc = lib.rbg_connector_rollout_gen(None, 8, 16, 10, C.byref(state), C.byref(state), one, 0, 5,
+                                       C.byref(params), None, None, None, None, C.byref(three), 0,
+                                       1, None)
+    assert rc == -3 and b"2 stash slots" in lib.rbg_last_error()
+    assert lib.rbg_connector_rollout_gen(None, 8, 16, 10, C.byref(state), C.byref(state), one, 0, 0,
+                                         C.byref(params), None, None, None, None, None, 0, 0,
+                                         None) == -3  # n_steps < 1
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: no file of the package may reference it."""
     pkg = os.path.join(ROOT, "routing_board_generation_amd")
