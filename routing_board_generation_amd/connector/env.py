@@ -134,6 +134,16 @@ class Connector:
         delay = self._prefetch_delay
         if delay is None:
             delay = self._gen.refill.get("every", 16) if self._gen is not None else 0
+            r = self._gen.refill if self._gen is not None else {}
+            if delay and not r.get("serial", True):
+                # rolling refills (ops.EpochStash): an entry is requested `depth` episodes before
+                # it is needed and becomes usable at most lead * K steps later, so with episodes
+                # of at most time_limit steps the period K must not exceed depth * time_limit /
+                # lead (measured at time limits 12 and 20: beyond it every reset misses and the
+                # stash falls back to in-line refills, 1.6-2x slower); 15 % to spare for episodes
+                # that end early.  Much shorter episodes (a trained policy) fall back at run time.
+                room = int(r.get("depth", 1) * self.time_limit * 0.85 / max(2, r.get("lead", 2)))
+                delay = max(1, min(delay, room))
         k = (B, device, fused_reset, delay, self._donate, self._aggregate,
              self.time_limit,
              self._reward_fn.timestep_reward, self._reward_fn.connected_reward)

@@ -633,9 +633,12 @@ class EpochStash:
     count (SeedExtension 1.4-1.8 ms, SequentialRandomWalk 0.4-0.5 ms) while leaving most of the
     chip idle: with one or two of them always in flight, generation keeps up with the ~85 boards
     per step that 4096 envs consume, at the price of ~6 us per step launch (two queues active).
-    It needs lead time: lead * K steps for the refill to finish, so depth - 1 episodes must
-    outlast (lead + 1) * K steps (tools/probe_overlap.py).  The requests of the
-    reset launch are served by one refill on the stepping stream itself (usable from tick 1)."""
+    It needs lead time: an entry requested at position p of epoch e is generated by the refill
+    queued behind that epoch and usable lead * K - p steps after its request, and the request
+    rule asks `depth` episodes ahead -- so `depth` consecutive episodes must outlast lead * K
+    steps (Connector sizes K by that, tools/probe_envgen.py --time-limit).  The
+    requests of the reset launch are served by one refill on the stepping stream itself (usable
+    from tick 1)."""
 
     def __init__(self, B: int, m: int, N: int, device, every: int, serial: bool = True,
                  depth: int = 1, gen: Optional[GeneratorSpec] = None,

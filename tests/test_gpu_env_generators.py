@@ -246,15 +246,18 @@ def test_fused_random_rollout_for_every_generator(rbg, oracle, name, prefetch, r
 
 
 def test_adaptive_refill_period_follows_short_episodes(rbg, oracle):
-    """The generator's default stash schedule refills every 48 steps, two episodes ahead; when
-    episodes are shorter than that (here 4 steps) resets miss the stash and run the generator
-    inside the step launch.  The session watches the miss counter and refills more often --
-    without any effect on the results (compared with the oracle throughout)."""
+    """The generator's default stash schedule is sized for episodes of about the time limit; when
+    episodes are much shorter than the schedule assumes (here 4 steps against a period of 32)
+    resets miss the stash and run the generator inside the step launch.  The session watches
+    the miss counter and refills more often -- without any effect on the results (compared with
+    the oracle throughout)."""
     from routing_board_generation_amd import ops
 
     m, N, B, tl, steps = 10, 4, 48, 4, 260
     gen, gen_fn = make_pair(rbg, oracle, "online_seq_rw", m, N)
-    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl))  # default schedule
+    # (the generator's rolling schedule with its period for 50-step episodes given explicitly:
+    # left to itself the env would shorten the period to fit a time limit of 4)
+    env = rbg.VmapAutoResetWrapper(rbg.Connector(generator=gen, time_limit=tl), prefetch_delay=32)
     keys, akeys = _keys(rbg, 71, B), _keys(rbg, 72, B)
     state, ts = env.reset(keys)
     est, ets = oracle_reset(oracle, gen_fn, to_np(keys))
@@ -438,16 +441,17 @@ def test_stash_request_rule_under_hits_and_misses(rbg, oracle, depth, delay, tl)
     sess.drain()
 
 
-@pytest.mark.parametrize("B,steps", [(192, 1500), (4096, 700)])
+@pytest.mark.parametrize("B,steps,tl", [(192, 1500, 50), (4096, 700, 50), (4096, 400, 20)])
 @pytest.mark.parametrize("name", ["online_parallel_rw", "online_seq_rw", "online_random_seed",
                                   "offline_seed_extension"])
-def test_long_runs_do_not_depend_on_the_stash_schedule(rbg, name, B, steps):
+def test_long_runs_do_not_depend_on_the_stash_schedule(rbg, name, B, steps, tl):
     """1500 auto-resetting steps (about 40 episodes per env) through the drop-in classes, once
     with every restart running the generator inline and once with the generator's default
     next-episode-stash schedule (output chunks reused, adaptive period): the same final State,
     the same reward total, the same number of episodes.  The B = 4096 rows are the benchmark's
     batch: the refills that roll beside the stepping stream (SequentialRandomWalk, SeedExtension)
-    then really overlap hundreds of step launches, and no host synchronisation paces them."""
+    then really overlap hundreds of step launches, and no host synchronisation paces them; with a
+    time limit of 20 the env shortens the refill period so that the rolling form still fits."""
     import torch
 
     from routing_board_generation_amd import ops
@@ -459,7 +463,8 @@ def test_long_runs_do_not_depend_on_the_stash_schedule(rbg, name, B, steps):
     for prefetch in (False, True):
         kw = dict(randomness=0.0, two_sided=True, number_of_boards=512) if name.startswith("offline") else {}
         env = rbg.VmapAutoResetWrapper(rbg.MultiToSingleWrapper(
-            rbg.Connector(generator=make_online_generator(name, m, N, **kw))), prefetch=prefetch)
+            rbg.Connector(generator=make_online_generator(name, m, N, **kw), time_limit=tl)),
+            prefetch=prefetch)
         policy = ops.RandomPolicy(akeys, N)
         state, ts = env.reset(keys)
         total = torch.zeros((B,), dtype=torch.float64, device=keys.device)
@@ -480,4 +485,4 @@ def test_long_runs_do_not_depend_on_the_stash_schedule(rbg, name, B, steps):
                 assert hits > 0.98 * int(episodes) and misses < 0.02 * int(episodes), (hits, misses)
     assert_dicts_equal(results[0][0], results[1][0], f"{name} final state.")
     assert (results[0][1] == results[1][1]).all() and results[0][2] == results[1][2]
-    assert results[0][2] > (steps // 60) * B
+    assert results[0][2] > (steps // (tl + 10)) * B

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--configs", default="0:1:1,16:1:1,16:1:2,48:1:2,16:0:1,16:0:2,32:0:2,48:0:2",
                     help="K:serial:depth[:lead[:streams]]; K = 0 is the inline (fused) reset; serial = 0: "
                          "rolling refills beside the stepping stream")
+    ap.add_argument("--time-limit", type=int, default=50)
     ap.add_argument("--warm", type=int, default=60, help="untimed steps before the timed window")
     ap.add_argument("--chunks", type=int, default=1, help="time the window in this many pieces")
     ap.add_argument("--flags", default="", help="extra hipcc flags: time a variant build of the "
@@ -52,7 +53,8 @@ def main():
         gen = make_online_generator(name, m, N, **kw).native_spec()
         # episodes of the timed window (the trajectory does not depend on the stash schedule)
         st, ts = ops.alloc_state(B, m, N, dev), ops.alloc_timestep(B, m, N, dev)
-        loop = ops.StepLoop(st, ts, keys, refill_every=0, fuse_policy=True, gen=gen)
+        loop = ops.StepLoop(st, ts, keys, refill_every=0, fuse_policy=True, gen=gen,
+                            time_limit=args.time_limit)
         loop.reset(keys)
         n_last = torch.zeros((), dtype=torch.int64, device=dev)
         for t in range(args.warm + args.steps):
@@ -65,7 +67,7 @@ def main():
             st, ts = ops.alloc_state(B, m, N, dev), ops.alloc_timestep(B, m, N, dev)
             loop = ops.StepLoop(st, ts, keys, refill_every=K, fuse_policy=True, gen=gen,
                                 serial_refill=bool(serial), stash_depth=depth, refill_lead=lead,
-                                refill_streams=streams)
+                                refill_streams=streams, time_limit=args.time_limit)
             loop.reset(keys)
             for t in range(args.warm):
                 loop.step(t)
@@ -91,7 +93,9 @@ def main():
             hits = int(loop.stash["hits"].sum().item()) if K else 0
             misses = int(loop.stash["misses"].sum().item()) if K else 0
             rows.append({"generator": name, "K": K, "serial": serial, "depth": depth,
-                         **({} if serial else {"lead": lead, "streams": streams}), "misses": misses,
+                         **({} if serial else {"lead": lead, "streams": streams,
+                                               "fell_back": loop._epochs.fell_back}),
+                         "time_limit": args.time_limit, "misses": misses,
                          "us_per_step": round(us, 2), "wall_us_per_step": round(wall / args.steps * 1e6, 2),
                          "env_steps_per_s": round(B / us * 1e6 / 1e6, 1),
                          "episodes": episodes, "stash_hits": hits,
