@@ -92,7 +92,7 @@ def main():
             us = e0.elapsed_time(e1) / args.steps * 1e3
             hits = int(loop.stash["hits"].sum().item()) if K else 0
             misses = int(loop.stash["misses"].sum().item()) if K else 0
-            rows.append({"generator": name, "K": K, "serial": serial, "depth": depth,
+            rows.append({"generator": name, "batch": B, "K": K, "serial": serial, "depth": depth,
                          **({} if serial else {"lead": lead, "streams": streams,
                                                "fell_back": loop._epochs.fell_back}),
                          "time_limit": args.time_limit, "misses": misses,
