@@ -172,8 +172,9 @@ def main() -> int:
         single = rnd.random() < 0.5
         gen, gen_fn = eg.make_pair(rbg, oracle, name, m, N)
         core = rbg.Connector(generator=gen, time_limit=tl)
+        donate = rnd.random() < 0.3  # the State advances in place, TimeStep buffers alternate
         env = rbg.VmapAutoResetWrapper(rbg.MultiToSingleWrapper(core) if single else core,
-                                       prefetch=prefetch, prefetch_delay=delay)
+                                       prefetch=prefetch, prefetch_delay=delay, donate=donate)
         if depth and env.unwrapped._gen is not None:
             env.unwrapped._gen.refill["depth"] = depth
         keys, akeys = keys_for(seed, B), keys_for(seed + 1, B)
@@ -193,7 +194,7 @@ def main() -> int:
             sess.drain()
         torch.cuda.synchronize()
         return dict(name=name, m=m, N=N, B=B, time_limit=tl, steps=steps, prefetch=prefetch,
-                    delay=delay, depth=depth, multi_to_single=single), B * steps
+                    delay=delay, depth=depth, multi_to_single=single, donate=donate), B * steps
 
     def case_rollout(seed):
         name = rnd.choice(eg.GENERATORS)
