@@ -430,6 +430,9 @@ def all_configs():
         elif kind == "seq":
             f = lambda: ops.seq_rw_generate(keys, m, N, split_first=True, want_solved=False)  # noqa
             cf = lambda: O.seq_rw_generator_batch(keys.cpu().numpy(), m, N, threads=threads)  # noqa
+        elif kind == "uniform":
+            f = lambda: ops.uniform_generate(keys, m, N)  # noqa
+            cf = lambda: O.generate_batch(keys.cpu().numpy(), m, N, "uniform", threads=threads, want_solved=False)  # noqa
         elif kind == "philox":  # the opt-in Philox stream of the walk (not the reference's process)
             f = lambda: ops.prw_generate_philox(keys, m, N)  # noqa
             cf = lambda: O.prw_philox_batch(keys.cpu().numpy(), m, N, threads=threads)  # noqa
@@ -455,6 +458,16 @@ def all_configs():
     gen_row("ref SeedExtension 10x10/5 B=100 (notebook batch: 427 ms on JAX-CPU)", 10, 5, 100,
             kind="seed_ext")
     gen_row("ref ParallelRandomWalk 10x10/5 B=100 (notebook batch: 19.7 ms on JAX-CPU)", 10, 5, 100)
+    # the rest of the reference's published timings (profiling_generators.ipynb):
+    # hardware unspecified, quoted for context only -- a single board is host-bound here
+    gen_row("ref ParallelRandomWalk 10x10/5 B=1 (notebook: 255 us on JAX-CPU)", 10, 5, 1)
+    gen_row("ref UniformRandomGenerator 10x10/5 B=100 (notebook batch: 4.18 ms)", 10, 5, 100,
+            kind="uniform")
+    gen_row("ref UniformRandomGenerator 10x10/5 B=1 (notebook: 213 us)", 10, 5, 1, kind="uniform")
+    gen_row("ref SequentialRandomWalk 10x10/5 B=100 (notebook cell failed; plot script: 515 ms)",
+            10, 5, 100, kind="seq")
+    gen_row("ref SequentialRandomWalk 10x10/5 B=1 (notebook: 685 us)", 10, 5, 1, kind="seq")
+    gen_row("ref SeedExtension 10x10/5 B=1 (notebook: 998 us)", 10, 5, 1, kind="seed_ext")
 
     # C3: env.step rollout, per-step API and fused
     B, m, N = 4096, 16, 10
