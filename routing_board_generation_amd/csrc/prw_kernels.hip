@@ -163,12 +163,23 @@ int fill_gen(const rbg_generator *gen, int m, int N, GenSpec *gs, int *prefix_co
   }
 }
 
+// Which instantiation of the step a stash needs: several slots per env, in-flight claims or far
+// keys take the deep form; no stash or a plain one takes the form that carries none of it.
+bool deep_stash(const StashPtrs &s) {
+#if defined(RBG_PROBE_DEEP_ALWAYS)  // developer probe (tools/ab_step.py --build): what the deep form costs a plain stash
+  return true;
+#endif
+  return s.tag && (s.depth > 1 || s.inflight || s.far_key);
+}
+
 template <int KIND>
 void launch_env_gen(const EnvArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   if (a.mode == kModeReset) {
     hipLaunchKernelGGL(connector_reset_gen_kernel<KIND>, grid, block, lds, st, a);
+  } else if (deep_stash(a.stash)) {
+    hipLaunchKernelGGL((connector_step_gen_kernel<KIND, true>), grid, block, lds, st, a);
   } else {
-    hipLaunchKernelGGL(connector_step_gen_kernel<KIND>, grid, block, lds, st, a);
+    hipLaunchKernelGGL((connector_step_gen_kernel<KIND, false>), grid, block, lds, st, a);
   }
 }
 
@@ -403,6 +414,8 @@ static int launch_env(EnvArgs &a, void *stream, const char *what) {
     launch_env_gen<kGenPhilox>(a, grid, block, lds, st);
   } else if (a.mode == kModeReset) {
     hipLaunchKernelGGL(connector_reset_kernel, grid, block, lds, st, a);
+  } else if (deep_stash(a.stash)) {
+    hipLaunchKernelGGL(connector_step_deep_kernel, grid, block, lds, st, a);
   } else {
     hipLaunchKernelGGL(connector_step_kernel, grid, block, lds, st, a);
   }

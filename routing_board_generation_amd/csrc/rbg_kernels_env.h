@@ -34,19 +34,14 @@ constexpr int kEnvWavesPerBlock = RBG_ENV_WPB;  // waves (envs) per workgroup of
 // of setup_train.py:112-152 get connector_{reset,step}_gen_kernel<KIND>.
 enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
 
-template <int MODE, int KIND>
+// DEEP (step only): the stash has several slots per env, in-flight claims or far keys (rolling
+// refills); false = no stash or a plain one, and the step carries nothing of the deep form -- its
+// probes, its request rule, its wave priority cost the plain form 0.5-1 us per launch in round 3.
+template <int MODE, int KIND, bool DEEP = true>
 __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 #if defined(RBG_PROBE_STEP_TIMES)  // developer probe (tools/probe_step.py --times)
   const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
 #endif
-  // Rolling refills (stash.inflight given: refills run beside the step launches): the step's
-  // waves outrank the refill's in issue arbitration.  A refill wave is the oldest wave on its
-  // SIMD for a millisecond and wins every cycle it is ready in; at equal priority a SeedExtension
-  // refill makes the step launches it overlaps 3-7x longer (13 -> 30-105 us), at priority 1 they
-  // take 17-18 us and the refill, which has slack, takes the rest (DESIGN.md 4.2a).
-  if constexpr (MODE == kModeStep) {
-    if (a.stash.inflight) __builtin_amdgcn_s_setprio(1);
-  }
   const int lane = threadIdx.x & (kWaveSize - 1);
   const SubWave<64> sw(lane);
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -100,13 +95,26 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
   } else if (lane < N) {
     act = a.action[(size_t)b * N + lane];
   }
-  const StashProbe probe = stash_probe_issue(a.stash, a.B, b, lane);  // in flight during the step
+  const StashProbe probe = stash_probe_issue<DEEP>(a.stash, a.B, b, lane);  // in flight during the step
+  // Rolling refills (stash.inflight given: refills run beside the step launches): the step's
+  // waves outrank the refill's in issue arbitration.  A refill wave is the oldest wave on its
+  // SIMD for a millisecond and wins every cycle it is ready in; at equal priority a SeedExtension
+  // refill makes the step launches it overlaps 3-7x longer (13 -> 30-105 us), at priority 1 they
+  // take 17-18 us and the refill, which has slack, takes the rest (DESIGN.md 4.2a).
+  // NOT at the kernel's entry: s_setprio has unmodelled side effects for the compiler, and a
+  // wave-uniform global load that follows one is no longer provably unclobbered -- it becomes a
+  // vector load + s_waitcnt + v_readfirstlane instead of an s_load.  Round 3 had it first thing,
+  // and State.step_count (needed for a branch) then cost every wave of the launch an exposed
+  // memory round trip before its grid load was even issued (12.1 -> 12.6-13.3 us).
+  if constexpr (DEEP) {
+    if (a.stash.inflight) __builtin_amdgcn_s_setprio(1);
+  }
   RowPrefetch pf;
   pf.row = -1;
   if (a.p.auto_reset && a.stash.tag && step_count + 1 >= a.p.time_limit && (g.m & 3) == 0 &&
       g.n <= 4 * kWaveSize)  // wave-uniform
     pf = stash_row_issue(a.stash.next, g, N,
-                         stash_probe_row(a.stash, probe, a.B, b, lane, key, a.tick), lane);
+                         stash_probe_row<DEEP>(a.stash, probe, a.B, b, lane, key, a.tick), lane);
 #if defined(RBG_PROBE_SKIP_STEP)  // developer probe: load -> store only (wrong results)
   StepResult res;
   res.was_connected = res.connected = res.done = res.last = false;
@@ -137,7 +145,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
     // episode's key and the refill that wrote it is known to have completed (ready_at: ordered
     // by the host through the stream, never through in-kernel flags).
     const int row = pf.row >= 0 ? pf.row
-                                : stash_probe_row(a.stash, probe, a.B, b, lane, key, a.tick);
+                                : stash_probe_row<DEEP>(a.stash, probe, a.B, b, lane, key, a.tick);
     if (pf.row >= 0) {
       stash_row_commit(sw, board, g, pf, ag, key);
       if (a.stash.hits && lane == 0) a.stash.hits[b] += 1;
@@ -151,7 +159,8 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
       key = regenerate_kind<64, KIND>(sw, board, W, g, N, rk, ag, a.gen);
     }
     step_count = 0;
-    request_refill<KIND>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay, row, true, probe.far);
+    request_refill<KIND, DEEP ? kMaxStashDepth : 1>(sw, a.stash, a.B, b, key,
+                                                    a.tick + a.ready_delay, row, true, probe.far);
     const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
     store_state(sw, board, g, N, b, ag, step_count, key, a.out);
     write_observation(sw, board, g, N, b, ag, step_count, a.ts, bits);
@@ -175,7 +184,11 @@ __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_obser
   connector_body<kModeObserve, kGenPrw>(a);
 }
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_kernel(EnvArgs a) {
-  connector_body<kModeStep, kGenPrw>(a);
+  connector_body<kModeStep, kGenPrw, false>(a);
+}
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_deep_kernel(
+    EnvArgs a) {
+  connector_body<kModeStep, kGenPrw, true>(a);
 }
 // Connector(generator = Uniform / SequentialRandomWalk / SeedExtension / offline dataset)
 template <int KIND>
@@ -183,10 +196,10 @@ __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset
     EnvArgs a) {
   connector_body<kModeReset, KIND>(a);
 }
-template <int KIND>
+template <int KIND, bool DEEP>
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_gen_kernel(
     EnvArgs a) {
-  connector_body<kModeStep, KIND>(a);
+  connector_body<kModeStep, KIND, DEEP>(a);
 }
 
 

@@ -44,21 +44,30 @@ struct StashProbe {
   int ready_at;
   uint2 far;  // lane 0: StashPtrs::far_key of the env (0 without one)
 };
+// DEEP = false: the launch was given no stash or a plain one (one slot per env, no in-flight claims,
+// no far keys -- what the walk's env path runs with), and the kernel carries none of the deep
+// stash's probes, request rule or priorities (the host picks the instantiation: launch_env).
+template <bool DEEP = true>
 __device__ __forceinline__ StashProbe stash_probe_issue(const StashPtrs &st, int B, int b,
                                                         int lane) {
   StashProbe p = {make_uint2(0u, 0u), 0x7FFFFFFF, make_uint2(0u, 0u)};
-  if (st.tag && lane < st.depth) {
+  if (st.tag && lane < (DEEP ? st.depth : 1)) {
     const int r = lane * B + b;
     p.tag = *reinterpret_cast<const uint2 *>(&st.tag[2 * (size_t)r]);
     p.ready_at = st.ready_at[r];
   }
-  if (st.far_key && lane == 0) p.far = *reinterpret_cast<const uint2 *>(&st.far_key[2 * (size_t)b]);
+  if constexpr (DEEP) {
+    if (st.far_key && lane == 0)
+      p.far = *reinterpret_cast<const uint2 *>(&st.far_key[2 * (size_t)b]);
+  }
   return p;
 }
+template <bool DEEP = true>
 __device__ __forceinline__ int stash_probe_row(const StashPtrs &st, const StashProbe &p, int B,
                                                int b, int lane, Key2 key, int tick) {
-  const bool ok = st.tag && lane < st.depth && tick >= p.ready_at && p.tag.x == key.a &&
-                  p.tag.y == key.b;
+  const bool ok = st.tag && lane < (DEEP ? st.depth : 1) && tick >= p.ready_at &&
+                  p.tag.x == key.a && p.tag.y == key.b;
+  if constexpr (!DEEP) return (__ballot(ok) & 1ull) ? b : -1;
   const uint32_t m = (uint32_t)__ballot(ok) & ((1u << kMaxStashDepth) - 1u);
   return m == 0u ? -1 : (31 - __builtin_clz(m)) * B + b;  // the later slot wins, as in stash_lookup
 }
@@ -139,6 +148,7 @@ __device__ __forceinline__ void request_refill(const SubWave<LPB> &sw, const Sta
     }
     return;
   }
+  if constexpr (MAXD == 1) return;  // (a kernel built for plain stashes: launch_env)
   if (st.far_key && hit_row >= 0) {  // (uniform in the sub-wave)
     Key2 far;
     if (have_far) {
