@@ -250,10 +250,22 @@ def rehearse_launch(args) -> None:
                                        "elapsed_s": 1.0 + rank, "launch_ms_max": launch_ms,
                                        "neg_launch_ms_min": -launch_ms})
     coll = sharding.collective_info()
+    # the two other readings of N > 1 (main(): generator_block): BASELINE configs[3] -- 4096 keys
+    # per rank of split(PRNGKey(0), 4096 N) at 32x32/20 -- and the strong reading -- the global
+    # batch of 4096 keys cut into N shards
+    blocks = {}
+    for name, total in (("c4", BATCH_PER_GPU * world), ("strong", BATCH_PER_GPU)):
+        blo, bhi = sharding.shard_bounds(total, rank, world)
+        bred = sharding.all_reduce_metrics({"boards": float((bhi - blo) * args.steps),
+                                            "elapsed_s": 1.0 + rank})
+        blocks[name] = {"global_batch": total, "boards": bred["boards"],
+                        "boards_per_gpu": bhi - blo,
+                        "elapsed_s_max_over_ranks": bred["elapsed_s"],
+                        "scaling": "weak" if name == "c4" else "strong"}
     if rank == 0:
         print(json.dumps({"metric": "boards_per_sec", "value": None, "unit": "boards/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "rehearsal": True, "boards": red["boards"],
+                          "rehearsal": True, "boards": red["boards"], **blocks,
                           "elapsed_s_max_over_ranks": red["elapsed_s"], "scaling": "weak",
                           "launch_ms_over_ranks": {"min": -red["neg_launch_ms_min"],
                                                    "max": red["launch_ms_max"]},
@@ -386,8 +398,15 @@ def env_steps_by_generator(keys, m, N, steps, close=None):
         for t in range(warm, warm + steps):
             loop.step(t)
         e1.record()
+        # host wall to the last STEP's completion (the stepping stream): the rolling generators'
+        # refills still in flight on their own streams belong to later steps -- a device-wide
+        # synchronize charged ~2 ms of them to 300 steps and read as "host-bound" in round 3
+        e1.synchronize()
+        wall = time.perf_counter() - t0
+        t_drain = time.perf_counter()
         el = close(t0) if close else None
         torch.cuda.synchronize(dev)
+        drain_ms = (time.perf_counter() - t_drain) * 1e3
         loop.drain()
         us = e0.elapsed_time(e1) / steps * 1e3
         rows[name] = {"us_per_step": us, "env_steps_per_s": B / us * 1e6,
@@ -399,8 +418,8 @@ def env_steps_by_generator(keys, m, N, steps, close=None):
                                  "misses": int(loop.stash["misses"].sum().item())}
                                 if sched["every"] else "none (the generator runs inside the step "
                                                        "launch of the envs that restart)")}
-        if el is not None:
-            rows[name]["host_wall_us_per_step"] = el / steps * 1e6
+        rows[name]["host_wall_us_per_step"] = wall / steps * 1e6
+        rows[name]["refills_in_flight_at_the_end_ms"] = drain_ms
     base = rows["online_parallel_rw"]["us_per_step"]
     for r in rows.values():
         r["vs_online_parallel_rw"] = r["us_per_step"] / base
@@ -692,6 +711,61 @@ def main() -> None:
         "launch_ms_max": kernel_avg_ms, "neg_launch_ms_min": -kernel_avg_ms}, device=dev)
     total_elapsed = metrics["elapsed_s"]  # max over ranks
     value = metrics["boards"] / total_elapsed
+
+    # ---------------------------------------------------------------- the other readings of N > 1
+    # `value` is the WEAK reading of BASELINE's "batch 4096, 1/2/4/8 GPU" (4096 boards per GPU).
+    # Beside it, timed exactly like it (barrier, local clock, K launches, local synchronize,
+    # MAX over ranks): BASELINE configs[3] and the strong reading of the same batch.
+    def generator_block(global_keys, gm, gn, steps, label):
+        shard = sharding.shard_keys(rbg.split(rbg.PRNGKey(0, device=dev), global_keys), rank, world)
+        o = ops.prw_generate(shard, gm, gn, split_first=True, want_solved=False, want_train=True,
+                             want_state=True, want_iters=True)
+        launch = ops.prw_generate_launcher(shard, gm, gn, True, o)
+        for _ in range(max(3, min(args.warmup, 20))):
+            launch()
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.record()
+        b1.record()
+        barrier()
+        tb = time.perf_counter()
+        b0.record()
+        for _ in range(steps):
+            launch()
+        b1.record()
+        el = close(tb)
+        ms = b0.elapsed_time(b1) / steps
+        red = sharding.all_reduce_metrics({"boards": float(shard.shape[0] * steps), "elapsed_s": el,
+                                           "launch_ms_max": ms, "neg_launch_ms_min": -ms},
+                                          device=dev)
+        return {"workload": label, "grid_size": gm, "num_agents": gn,
+                "global_batch": int(global_keys), "boards_per_gpu": int(shard.shape[0]),
+                "keys": f"split(PRNGKey(0), {global_keys}), rank g takes shard g "
+                        "(sharding.shard_keys = reset_keys.reshape(devices, per_device, 2), "
+                        "setup_train.py:396-400)",
+                "value": red["boards"] / red["elapsed_s"], "unit": "boards/s", "steps": steps,
+                "ms_per_step": red["elapsed_s"] / steps * 1e3,
+                "launch_ms_over_ranks": {"min": -red["neg_launch_ms_min"],
+                                         "max": red["launch_ms_max"]}}
+
+    scaling_blocks = None
+    if args.mode in ("all", "generator"):
+        scaling_blocks = {
+            "c4": {**generator_block(4096 * world, 32, 20, max(1, min(args.steps, 100)),
+                                     "ParallelRandomWalkGenerator 32x32 grid, 20 agents, 4096 "
+                                     "keys per GPU (BASELINE configs[3]: at 8 GPUs the 32 768-key "
+                                     "batch, batch-sharded)"),
+                   "scaling": "weak"},
+            "strong": {**generator_block(BATCH_PER_GPU, GRID, AGENTS, args.steps,
+                                         "ParallelRandomWalkGenerator 16x16 grid, 10 agents, "
+                                         "GLOBAL batch 4096 cut into one shard per GPU "
+                                         "(512 boards per GPU at 8 GPUs)"),
+                       "scaling": "strong"},
+            "note": "`value` of the line is the weak reading of BASELINE's \"batch 4096, 1/2/4/8 "
+                    "GPU\" (4096 boards per GPU, global batch 4096 x N); `strong` is the other "
+                    "reading (global batch 4096 whatever N; a launch of 512 boards lasts as long "
+                    "as its slowest board, so this reading cannot scale and says so); `c4` is the "
+                    "one BASELINE config that is multi-GPU by definition.  Same timing rule as "
+                    "`value`; per GPU both generate disjoint shards with no data-path collective."}
 
     # What actually bounds the launch: the serial latency of its longest board.  Timed live: the
     # board with the most walk iterations launched ALONE (one wave), same kernel, same outputs.
@@ -1128,6 +1202,10 @@ def main() -> None:
         }
         if peaks is not None:
             line["roofline"]["peak_measured"] = peaks
+        if scaling_blocks is not None:
+            line["c4"] = scaling_blocks["c4"]
+            line["strong"] = scaling_blocks["strong"]
+            line["scaling_readings"] = scaling_blocks["note"]
         if philox is not None:
             line["philox_stream"] = philox
         if pipelined is not None:

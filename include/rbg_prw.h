@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBG_ABI_VERSION 8
+#define RBG_ABI_VERSION 9
 
 #define RBG_E_NULL (-1)   /* a required pointer is NULL */
 #define RBG_E_SHAPE (-2)  /* B, m, N or num out of range */
@@ -224,6 +224,10 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  * the envs that restarted recently (a throughput-shaped batch of walks) instead of by every step
  * launch for its own few finished envs (a launch that lasts as long as its longest walk); the
  * step then copies 1.3 KB instead of walking.
+ *   (tick, ready_delay: int32, 0 <= tick, 0 <= ready_delay, tick + ready_delay <= INT32_MAX, else
+ *   RBG_E_PARAM.  A session that outlives 2^31 launches rebases: between two launches, with no
+ *   refill in flight, subtract one offset from its tick and from every ready_at (clamped at 0) --
+ *   routing_board_generation_amd.session.EpochStash does at tick 2^30.)
  *   depth       slots per env, 1 .. 12; slot s of env b is row s * B + b of every array below
  *   next        a full rbg_state of depth * B rows: next[r] = reset(split(tag[r])[0])
  *   tag         uint32 [depth*B][2]: the State.key next[r] was generated for (zero-initialised)
@@ -232,10 +236,11 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  *   hits        int32 [B], nullable: resets served from the stash (diagnostics; caller zeroes)
  *   misses      int32 [B], nullable: resets of a stash-backed launch that had to run the generator
  *               inline (caller zeroes; a host that sees them grow refills more often)
- *   inflight    int32 [depth*B], nullable (zero-initialised): 1 while a listed refill is
- *               generating the row.  Needed when refills overlap each other (rolling refills on
- *               side streams, below): rbg_stash_list skips such rows, so that nothing is generated
- *               twice and two producers never write one row at the same time
+ *   inflight    int32 [depth*B], nullable (zero-initialised): non-zero while a listed refill is
+ *               generating the row (the value is the claim_ready of the list that claimed it).
+ *               Needed when refills overlap each other (rolling refills on side streams, below):
+ *               rbg_stash_list skips such rows, so that nothing is generated twice and two
+ *               producers never write one row at the same time
  *   far_key     uint32 [B][2], nullable: the farthest key env b holds a request for.  With it a
  *               restart that took its State from the stash makes its one new request --
  *               f(far) into the row it consumed -- without re-deriving the chain (deep stashes:
@@ -477,16 +482,51 @@ int rbg_connector_step_call(const rbg_step_call *call);
  * neither it nor the step launches are slowed much by the other):
  *   rbg_stash_list            lists the rows with a pending request (tag != refill_key) that no
  *                             earlier refill is still generating into stash->scratch ([0] = count)
- *                             and marks them in stash->inflight.  Calls must be stream-ordered
- *                             among themselves (one "listing" stream); each in-flight refill
+ *                             and claims them in stash->inflight.  Calls must be stream-ordered
+ *                             among themselves (one "listing" order); each in-flight refill
  *                             needs a scratch area of its own (pass a copy of the struct).
- *   rbg_stash_refill_listed   generates exactly the listed rows and releases them.
+ *   rbg_stash_refill_listed   generates exactly the listed rows and releases them (tag, then the
+ *                             claim, release-ordered; the list reads the claim first, acquire).
  * Ordering contract (host, events): a list call follows the launches whose requests it is to
  * see; its producer follows it; the launch that may consume a row (ready_at) follows the
- * producer.  Nothing else: requests written while a refill runs are simply seen by a later one. */
-int rbg_stash_list(int B, int m, int N, const rbg_stash *stash, void *stream);
+ * producer.  Requests written while a refill runs are simply seen by a later list.
+ * ready_at stays truthful under re-assignment: claim_ready = the ready_at carried by the requests
+ * this list serves (tick + ready_delay of the launches since the previous list, >= 1), skip_ready
+ * = the ready_at of the requests the NEXT list will serve (>= claim_ready).  A row that is skipped
+ * because an earlier refill is still generating it, although its request is newer than that
+ * refill's claim (ready_at > the claim's value: the env re-assigned the row while its producer
+ * ran), can only be generated by the next list's producer, so its ready_at is raised to
+ * skip_ready.  Without in-flight claims (stash->inflight NULL) both values are ignored. */
+int rbg_stash_list(int B, int m, int N, const rbg_stash *stash, int claim_ready, int skip_ready,
+                   void *stream);
 int rbg_stash_refill_listed(const rbg_generator *generator, int B, int m, int N,
                             const rbg_stash *stash, void *stream);
+
+/* One epoch boundary of the rolling form in ONE call, for hosts whose FFI and event API cost
+ * microseconds per operation (Python: five event operations, two library calls and the miss
+ * counter's snapshot came to ~80 us per refill).  In this order:
+ *   record `launched` on step_stream; step_stream waits for `await_done` (nullable: the refill
+ *   whose rows the NEXT launch may be the first to consume); gen_stream waits for `launched` and
+ *   for `after_listed` (nullable: the previous refill's list); on gen_stream: rbg_stash_list
+ *   (claim_ready, skip_ready), the miss snapshot (optional, below), record `listed`,
+ *   rbg_stash_refill_listed, record `done`.
+ * All events are hipEvent_t owned by the caller.  Miss snapshot (miss_word non-NULL): the list
+ * launch also sums stash->misses into *miss_acc (device, zero before the first call; cleared by
+ * the call), one more tiny launch writes (sum << 20 | stamp & 0xFFFFF) to *miss_word (device) and
+ * 8 bytes are copied to *miss_host (pinned host memory) on gen_stream -- never a synchronisation;
+ * the host reads whatever has arrived (schedule.MissWatch). */
+typedef struct rbg_stash_roll_call {
+  const rbg_generator *generator; /* NULL = ParallelRandomWalk */
+  int32_t B, m, N;
+  int32_t claim_ready, skip_ready;
+  uint32_t stamp;
+  const rbg_stash *stash; /* with the scratch area of THIS refill; inflight required */
+  void *step_stream, *gen_stream;
+  void *launched, *await_done, *after_listed, *listed, *done; /* hipEvent_t */
+  int64_t *miss_acc, *miss_word; /* device, nullable together */
+  int64_t *miss_host;            /* pinned host */
+} rbg_stash_roll_call;
+int rbg_stash_roll(const rbg_stash_roll_call *call);
 
 /* rbg_stash_refill with the generator's own producer: next[r] = generator(split(refill_key[r])[0])
  * for every row with tag[r] != refill_key[r]. */

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "librbg_prw.so")
 SRC_PATH = os.path.join(_PKG, "csrc", "prw_kernels.hip")
 HEADER_PATH = os.path.join(_ROOT, "include", "rbg_prw.h")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 # -amdgpu-sched-strategy=max-ilp: the walk's straggler boards run one wave per SIMD, where an
 # instruction that depends on its predecessor issues after ~8 cycles and an independent one after
 # ~4 (tools/microbench/dep_latency.hip); the default scheduler (occupancy-first) leaves the
@@ -82,6 +82,16 @@ class StepCall(C.Structure):
                 ("params", EnvParams), ("stash", C.POINTER(Stash)), ("stream", C.c_void_p)]
 
 
+class StashRollCall(C.Structure):
+    """include/rbg_prw.h::rbg_stash_roll_call"""
+    _fields_ = [("generator", C.POINTER(Generator)), ("B", C.c_int32), ("m", C.c_int32),
+                ("N", C.c_int32), ("claim_ready", C.c_int32), ("skip_ready", C.c_int32),
+                ("stamp", C.c_uint32), ("stash", C.POINTER(Stash)), ("step_stream", C.c_void_p),
+                ("gen_stream", C.c_void_p), ("launched", C.c_void_p), ("await_done", C.c_void_p),
+                ("after_listed", C.c_void_p), ("listed", C.c_void_p), ("done", C.c_void_p),
+                ("miss_acc", C.c_void_p), ("miss_word", C.c_void_p), ("miss_host", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/rbg_prw.h one to one
 SIGNATURES = {
     "rbg_abi_version": (C.c_int, []),
@@ -146,7 +156,9 @@ SIGNATURES = {
                                          C.POINTER(Timestep), C.POINTER(Stash), C.c_int, C.c_int,
                                          C.c_void_p]),
     "rbg_connector_step_call": (C.c_int, [C.POINTER(StepCall)]),
-    "rbg_stash_list": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Stash), C.c_void_p]),
+    "rbg_stash_list": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Stash), C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "rbg_stash_roll": (C.c_int, [C.POINTER(StashRollCall)]),
     "rbg_stash_refill_listed": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,
                                           C.POINTER(Stash), C.c_void_p]),
     "rbg_stash_refill_gen": (C.c_int, [C.POINTER(Generator), C.c_int, C.c_int, C.c_int,

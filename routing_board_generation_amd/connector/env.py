@@ -128,7 +128,11 @@ class Connector:
         """The launch context of batched reset/step calls (ops.ConnectorSession), one per batch
         size / device / wrapper configuration."""
         hot = self._hot
-        if hot is not None and hot[0] == B and hot[1] == device:
+        rf = self._reward_fn
+        if (hot is not None and hot[0] == B and hot[1] == device and hot[3] == self.time_limit
+                and hot[4] == rf.timestep_reward and hot[5] == rf.connected_reward):
+            # (time_limit and the reward function are public attributes a caller may change
+            # between calls: they are part of the key, not only of the session table's)
             return hot[2]
         fused_reset = self._auto_reset and self._gen is not None
         delay = self._prefetch_delay
@@ -161,7 +165,7 @@ class Connector:
                 self._reward_fn.timestep_reward, self._reward_fn.connected_reward,
                 auto_reset=fused_reset, refill_every=delay, donate=self._donate,
                 aggregate=self._aggregate, gen=self._gen, chunk_steps=self._chunk_steps)
-        self._hot = (B, device, sess)
+        self._hot = (B, device, sess, self.time_limit, rf.timestep_reward, rf.connected_reward)
         return sess
 
     # ---------------------------------------------------------------------------------- specs
@@ -258,11 +262,20 @@ class Connector:
         return epochs
 
     def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,
-                       want_timestep: bool = False):
+                       want_timestep: bool = False, record: bool = False):
         """n_steps of `step` under the masked-uniform random policy (ops.random_actions) in ONE
         kernel launch: the rollout loop of benchmark_on_random_agent.py:59-102 with jumanji's
         RandomAgent.  Batched states only.  Returns (state, stats, timestep-of-the-last-step or
-        None); stats are per-env int32 counters (include/rbg_prw.h::rbg_rollout_stats)."""
+        None); stats are per-env int32 counters (include/rbg_prw.h::rbg_rollout_stats).
+        record=True is the round-2 spelling of random_rollout_record (deprecated): it returns
+        that call's (state, actions, trajectory) without the stats, as it did then."""
+        if record:
+            import warnings
+
+            warnings.warn("random_rollout(record=True) is deprecated: call random_rollout_record, "
+                          "which also returns the rollout stats", DeprecationWarning, stacklevel=2)
+            so, _, actions, traj = self.random_rollout_record(state, policy_keys, t0, n_steps)
+            return so, actions, traj
         epochs = self._rollout_epochs_for(state)
         so, stats, ts = ops.connector_rollout(
             _state_bufs(state, True), policy_keys.contiguous(), t0, n_steps, self.time_limit,

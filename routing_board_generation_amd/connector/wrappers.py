@@ -70,9 +70,11 @@ class VmapAutoResetWrapper(_Wrapper):
         return self._env.step(state, action)
 
     def random_rollout(self, state: State, policy_keys: torch.Tensor, t0: int, n_steps: int,
-                       want_timestep: bool = False):
-        """n_steps of auto-resetting random-policy stepping in one launch (Connector.random_rollout)."""
-        return self._env.unwrapped.random_rollout(state, policy_keys, t0, n_steps, want_timestep)
+                       want_timestep: bool = False, record: bool = False):
+        """n_steps of auto-resetting random-policy stepping in one launch (Connector.random_rollout;
+        record=True: the deprecated round-2 spelling of random_rollout_record)."""
+        return self._env.unwrapped.random_rollout(state, policy_keys, t0, n_steps, want_timestep,
+                                                  record)
 
     def random_rollout_record(self, state: State, policy_keys: torch.Tensor, t0: int,
                               n_steps: int):

@@ -163,13 +163,14 @@ int fill_gen(const rbg_generator *gen, int m, int N, GenSpec *gs, int *prefix_co
   }
 }
 
-// Which instantiation of the step a stash needs: several slots per env, in-flight claims or far
-// keys take the deep form; no stash or a plain one takes the form that carries none of it.
+// Which instantiation of the step a stash needs: several slots per env or in-flight claims
+// (refills beside the steps) take the deep form; no stash or a plain one -- one slot per env,
+// refilled in line: far keys are never read at depth 1 -- takes the form that carries none of it.
 bool deep_stash(const StashPtrs &s) {
 #if defined(RBG_PROBE_DEEP_ALWAYS)  // developer probe (tools/ab_step.py --build): what the deep form costs a plain stash
   return true;
 #endif
-  return s.tag && (s.depth > 1 || s.inflight || s.far_key);
+  return s.tag && (s.depth > 1 || s.inflight);
 }
 
 template <int KIND>
@@ -427,6 +428,17 @@ int rbg_connector_reset(const uint32_t *keys, int B, int m, int N, const rbg_sta
   return rbg_connector_reset_gen(nullptr, keys, B, m, N, state, timestep, nullptr, 0, 0, stream);
 }
 
+// Launch ticks are int32 in the ABI and ready_at = tick + ready_delay must not wrap: a host whose
+// session outlives 2^31 launches rebases its ticks (and the stash's ready_at) long before
+// (include/rbg_prw.h::rbg_stash; session.EpochStash does at 2^30).
+static int check_tick(int tick, int ready_delay, const char *who) {
+  if (tick < 0 || ready_delay < 0 || tick > INT32_MAX - ready_delay) {
+    snprintf(g_err, sizeof(g_err), "%s: tick / ready_delay out of range (rebase the ticks)", who);
+    return RBG_E_PARAM;
+  }
+  return 0;
+}
+
 static int fill_stash(const rbg_stash *stash, StashPtrs *out, const char *who) {
   if (!stash) return 0;
   if (!state_complete(&stash->next) || !stash->tag || !stash->ready_at || !stash->refill_key) {
@@ -473,6 +485,8 @@ int rbg_connector_reset_gen(const rbg_generator *generator, const uint32_t *keys
   if (int rc = check_align(a.g, state->grid, timestep->obs_grid, stash ? stash->next.grid : nullptr))
     return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_connector_reset")) return rc;
+  if (stash)
+    if (int rc = check_tick(tick, ready_delay, "rbg_connector_reset")) return rc;
   a.keys = keys; a.B = B; a.N = N; a.out = to_ptrs(state); a.in = a.out;
   a.ts = to_ptrs(timestep); a.mode = kModeReset; a.tick = tick; a.ready_delay = ready_delay;
   return launch_env(a, stream, "rbg_connector_reset");
@@ -516,6 +530,8 @@ int rbg_connector_step_gen(const rbg_generator *generator, int B, int m, int N,
   if (stash)
     if (int rc = check_align(a.g, stash->next.grid, nullptr, nullptr)) return rc;
   if (int rc = fill_stash(stash, &a.stash, "rbg_connector_step")) return rc;
+  if (stash)
+    if (int rc = check_tick(tick, ready_delay, "rbg_connector_step")) return rc;
   a.B = B; a.N = N; a.in = to_ptrs(state_in); a.out = to_ptrs(state_out); a.action = action;
   a.policy_keys = policy_keys; a.policy_t = policy_t;
   a.p = *params; a.ts = to_ptrs(timestep); a.mode = kModeStep; a.tick = tick;
@@ -530,7 +546,8 @@ int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream) 
 // mode 0: scan every row (listing SeedExtension's first when a scratch area is given: dense
 // packing); 1: list only; 2: generate the listed rows
 static int stash_refill_impl(const rbg_generator *generator, int B, int m, int N,
-                             const rbg_stash *stash, void *stream, int mode) {
+                             const rbg_stash *stash, void *stream, int mode, int claim_ready = 1,
+                             int skip_ready = 0, unsigned long long *miss_acc = nullptr) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_stash_refill: B < 0");
   RefillArgs a;
   memset(&a, 0, sizeof(a));
@@ -575,8 +592,14 @@ static int stash_refill_impl(const rbg_generator *generator, int B, int m, int N
   if (int rc = fill_stash(stash, &a.stash, "rbg_stash_refill")) return rc;
   if (mode != 0 && !a.stash.scratch)
     return fail(RBG_E_NULL, "rbg_stash_list / rbg_stash_refill_listed: the stash has no scratch area");
+  if (mode == 1 && a.stash.inflight && (claim_ready < 1 || skip_ready < claim_ready))
+    return fail(RBG_E_PARAM, "rbg_stash_list: need 1 <= claim_ready <= skip_ready");
   a.B = B * stash->depth;  // the kernel works on rows
   a.N = N;
+  a.envs = B;
+  a.claim_ready = claim_ready;
+  a.skip_ready = skip_ready;
+  a.miss_acc = mode == 1 ? miss_acc : nullptr;
   const int envs_per_block = wpb * (kWaveSize / lpb);
   dim3 grid((a.B + envs_per_block - 1) / envs_per_block), block(kWaveSize * wpb);
   hipStream_t st = (hipStream_t)stream;
@@ -636,8 +659,45 @@ int rbg_stash_refill_gen(const rbg_generator *generator, int B, int m, int N,
   return stash_refill_impl(generator, B, m, N, stash, stream, 0);
 }
 
-int rbg_stash_list(int B, int m, int N, const rbg_stash *stash, void *stream) {
-  return stash_refill_impl(nullptr, B, m, N, stash, stream, 1);
+int rbg_stash_list(int B, int m, int N, const rbg_stash *stash, int claim_ready, int skip_ready,
+                   void *stream) {
+  return stash_refill_impl(nullptr, B, m, N, stash, stream, 1, claim_ready, skip_ready);
+}
+
+// One epoch boundary of the rolling form (include/rbg_prw.h::rbg_stash_roll_call): what
+// session.EpochStash queued with five event operations, two library calls and three torch kernels
+// from Python.
+int rbg_stash_roll(const rbg_stash_roll_call *c) {
+  if (!c) return fail(RBG_E_NULL, "rbg_stash_roll: NULL call");
+  if (!c->stash || !c->launched || !c->listed || !c->done)
+    return fail(RBG_E_NULL, "rbg_stash_roll: NULL stash / event");
+  if (!c->stash->inflight || !c->stash->scratch)
+    return fail(RBG_E_NULL, "rbg_stash_roll: the stash has no in-flight claims / scratch area");
+  if (c->miss_word && (!c->miss_acc || !c->miss_host))
+    return fail(RBG_E_NULL, "rbg_stash_roll: incomplete miss snapshot (acc, word, host)");
+  hipStream_t step = (hipStream_t)c->step_stream, gen = (hipStream_t)c->gen_stream;
+  const char *who = "rbg_stash_roll";
+  if (int rc = check_hip(hipEventRecord((hipEvent_t)c->launched, step), who)) return rc;
+  if (c->await_done)
+    if (int rc = check_hip(hipStreamWaitEvent(step, (hipEvent_t)c->await_done, 0), who)) return rc;
+  if (int rc = check_hip(hipStreamWaitEvent(gen, (hipEvent_t)c->launched, 0), who)) return rc;
+  if (c->after_listed)
+    if (int rc = check_hip(hipStreamWaitEvent(gen, (hipEvent_t)c->after_listed, 0), who)) return rc;
+  if (int rc = stash_refill_impl(nullptr, c->B, c->m, c->N, c->stash, gen, 1, c->claim_ready,
+                                 c->skip_ready,
+                                 c->miss_word ? (unsigned long long *)c->miss_acc : nullptr))
+    return rc;
+  if (c->miss_word && c->B > 0) {
+    hipLaunchKernelGGL(stash_miss_pack_kernel, dim3(1), dim3(1), 0, gen,
+                       (unsigned long long *)c->miss_acc, (unsigned long long *)c->miss_word,
+                       c->stamp);
+    if (int rc = check_hip(hipGetLastError(), who)) return rc;
+    if (int rc = check_hip(hipMemcpyAsync(c->miss_host, c->miss_word, sizeof(int64_t),
+                                          hipMemcpyDeviceToHost, gen), who)) return rc;
+  }
+  if (int rc = check_hip(hipEventRecord((hipEvent_t)c->listed, gen), who)) return rc;
+  if (int rc = stash_refill_impl(c->generator, c->B, c->m, c->N, c->stash, gen, 2)) return rc;
+  return check_hip(hipEventRecord((hipEvent_t)c->done, gen), who);
 }
 
 int rbg_stash_refill_listed(const rbg_generator *generator, int B, int m, int N,
@@ -749,6 +809,8 @@ int rbg_connector_rollout_gen(const rbg_generator *generator, int B, int m, int 
   if (int rc = fill_stash(stash, &a.stash, "rbg_connector_rollout_prefetch")) return rc;
   if (stash && stash->depth > kRolloutStashDepth)
     return fail(RBG_E_PARAM, "rbg_connector_rollout: at most 2 stash slots per env in a rollout launch");
+  if (stash)
+    if (int rc = check_tick(tick, ready_delay, "rbg_connector_rollout")) return rc;
   a.tick = tick; a.ready_delay = ready_delay;
   const bool wants_stats = stats && (stats->episodes || stats->connections_made ||
                                      stats->unconnected_agent_steps || stats->final_connections ||

@@ -34,8 +34,8 @@ constexpr int kEnvWavesPerBlock = RBG_ENV_WPB;  // waves (envs) per workgroup of
 // of setup_train.py:112-152 get connector_{reset,step}_gen_kernel<KIND>.
 enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
 
-// DEEP (step only): the stash has several slots per env, in-flight claims or far keys (rolling
-// refills); false = no stash or a plain one, and the step carries nothing of the deep form -- its
+// DEEP (step only): the stash has several slots per env or in-flight claims (rolling refills);
+// false = no stash or a plain one, and the step carries nothing of the deep form -- its
 // probes, its request rule, its wave priority cost the plain form 0.5-1 us per launch in round 3.
 template <int MODE, int KIND, bool DEEP = true>
 __device__ __forceinline__ void connector_body(const EnvArgs &a) {
@@ -212,6 +212,11 @@ struct RefillArgs {
   StashPtrs stash;
   GenSpec gen;
   int listed;  // the rows to generate are listed in stash.scratch (stash_list_kernel ran)
+  // stash_list_kernel with in-flight claims (rolling refills; include/rbg_prw.h::rbg_stash_list)
+  int claim_ready;  // ready_at of the requests this list serves (>= 1): the value a claim carries
+  int skip_ready;   // ready_at of the requests the NEXT list will serve
+  int envs;         // B (a.B counts rows = depth * B here)
+  unsigned long long *miss_acc;  // nullable: += sum of stash.misses (rbg_stash_roll's snapshot)
 };
 
 template <int LPB>
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
   split2_lanes(sw, key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
   const Key2 next_key = regenerate(sw, board, W, g, a.N, rk, ag);
   store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
+  __threadfence();  // the tag publishes a complete row (release; consumers are ordered by the host)
   if (sw.l == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
 }
 
@@ -242,19 +248,41 @@ __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
 // Rows with a pending request (tag != refill_key), listed for a dense packing of the producer's
 // wavefronts: scratch[0] = their number (zeroed by the host before), scratch[1..] = the rows, in
 // no particular order (which rows share a wavefront does not matter to any result).
+// With in-flight claims (stash.inflight: refills overlap each other and the step launches):
+//   * the claim is read FIRST, with acquire semantics -- the producer publishes tag -> fence ->
+//     inflight = 0 (release), so a row seen released is seen with the tag its producer wrote, and
+//     nothing is listed (generated) twice;
+//   * a claim carries the ready tick of the requests its list served (claim_ready).  A row that is
+//     skipped because an earlier refill is still generating it, but whose request is NEWER than
+//     that claim (ready_at > claim: the env re-assigned the row while its producer ran -- after a
+//     miss, request_refill's general rule may do that), will only be listed by the next list, so
+//     its ready_at moves on to that list's tick (skip_ready): ready_at stays truthful -- a launch
+//     that passes `tick >= ready_at` is ordered, by the host's events, behind the producer that
+//     wrote the row it finds (include/rbg_prw.h::rbg_stash_list).
 __global__ void stash_list_kernel(RefillArgs a) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   bool need = false;
   if (r < a.B) {
+    int claim = 0;
+    if (a.stash.inflight)
+      claim = __hip_atomic_load(&a.stash.inflight[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     const uint2 want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)r]);
     const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)r]);
     need = want.x != have.x || want.y != have.y;
-    // a row that an earlier, still running refill is generating is left alone: two producers
-    // never write one row at a time, and nothing is generated twice (include/rbg_prw.h)
     if (need && a.stash.inflight) {
-      need = a.stash.inflight[r] == 0;
-      if (need) a.stash.inflight[r] = 1;
+      if (claim != 0) {  // an earlier, still running refill is generating the row: leave it alone
+        need = false;
+        const int ready = a.stash.ready_at[r];
+        if (ready > claim && ready < a.skip_ready) a.stash.ready_at[r] = a.skip_ready;
+      } else {
+        a.stash.inflight[r] = a.claim_ready > 0 ? a.claim_ready : 1;
+      }
     }
+  }
+  if (a.miss_acc) {  // rbg_stash_roll: the stash's miss counter summed on the way (one atomic per wave)
+    unsigned long long v = r < a.envs && a.stash.misses ? (unsigned long long)a.stash.misses[r] : 0ull;
+    for (int off = kWaveSize / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & (kWaveSize - 1)) == 0 && v != 0ull) atomicAdd(a.miss_acc, v);
   }
   const uint64_t m = __ballot(need);
   if (m == 0ull) return;
@@ -263,6 +291,13 @@ __global__ void stash_list_kernel(RefillArgs a) {
   if (lane == 0) base = atomicAdd(&a.stash.scratch[0], __popcll(m));
   base = __builtin_amdgcn_readfirstlane(base);
   if (need) a.stash.scratch[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+}
+
+// (misses << 20 | stamp) as ONE 8-byte word for the host (schedule.MissWatch), accumulator cleared
+__global__ void stash_miss_pack_kernel(unsigned long long *acc, unsigned long long *word,
+                                       uint32_t stamp) {
+  *word = (*acc << 20) | (unsigned long long)(stamp & 0xFFFFFu);
+  *acc = 0ull;
 }
 
 template <int LPB, int KIND>
@@ -306,12 +341,11 @@ __global__ __launch_bounds__(kBlock) void stash_refill_gen_kernel(RefillArgs a) 
       const Key2 next_key = regenerate_kind<LPB, KIND>(sw, board, W, g, a.N, rk, ag, a.gen);
       if (need) {
         store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
+        __threadfence();  // the tag publishes a complete row
         if (sw.l == 0) {
           *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
-          if (a.listed && a.stash.inflight) {
-            __threadfence();  // whoever sees the row released also sees its tag
-            a.stash.inflight[b] = 0;
-          }
+          if (a.listed && a.stash.inflight)  // release: whoever sees the row released sees its tag
+            __hip_atomic_store(&a.stash.inflight[b], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }

@@ -44,9 +44,9 @@ struct StashProbe {
   int ready_at;
   uint2 far;  // lane 0: StashPtrs::far_key of the env (0 without one)
 };
-// DEEP = false: the launch was given no stash or a plain one (one slot per env, no in-flight claims,
-// no far keys -- what the walk's env path runs with), and the kernel carries none of the deep
-// stash's probes, request rule or priorities (the host picks the instantiation: launch_env).
+// DEEP = false: the launch was given no stash or a plain one (one slot per env, no in-flight
+// claims -- what the walk's env path runs with), and the kernel carries none of the deep stash's
+// probes, request rule or priorities (the host picks the instantiation: launch_env).
 template <bool DEEP = true>
 __device__ __forceinline__ StashProbe stash_probe_issue(const StashPtrs &st, int B, int b,
                                                         int lane) {

@@ -27,32 +27,58 @@ class BoardDatasetGeneratorJAX(Generator):
                  number_of_boards: int = 10000, generate_solved_boards: bool = False,
                  device=None) -> None:
         super().__init__(grid_size, num_agents)
+        if board_name not in ("offline_seed_extension", "offline_uniform", "offline_parallel_rw"):
+            # the reference's else-branch would run ParallelRandomWalk for ANY other string; a
+            # typo silently changing the generator is not worth mirroring
+            raise ValueError(f"unknown board_name {board_name!r}")
         self.board_name = board_name
-        keys = split(PRNGKey(0, device=device), number_of_boards)  # :57-58, :76
-        if board_name == "offline_seed_extension":
+        self.device = device
+        if board_name != "offline_parallel_rw":  # (:36-52: kept as attributes for these two)
             self.randomness = randomness
             self.two_sided = two_sided
             self.extension_iterations = extension_iterations
             self.extension_steps = extension_steps
+        # :57-63 -- the dataset is generate_n_boards(PRNGKey(0), number_of_boards, ...)
+        self._heads, self._targets, solved = self._generate(
+            split(PRNGKey(0, device=device), number_of_boards), generate_solved_boards)
+        self.solved_boards = solved
+
+    def _generate(self, keys: torch.Tensor, generate_solved_boards: bool):
+        """One batched launch over `keys` [n, 2]: (heads [n, N, 2], targets [n, N, 2] agent-major,
+        solved boards [n, m, m] or None)."""
+        m, N = self.grid_size, self.num_agents
+        if self.board_name == "offline_seed_extension":
             out = ops.seed_extension_generate(
-                keys, grid_size, num_agents, split_first=False, randomness=randomness,
-                two_sided=two_sided, extension_iterations=extension_iterations,
-                extension_steps=extension_steps, want_solved=bool(generate_solved_boards),
+                keys, m, N, split_first=False, randomness=self.randomness,
+                two_sided=self.two_sided, extension_iterations=self.extension_iterations,
+                extension_steps=self.extension_steps, want_solved=bool(generate_solved_boards),
                 want_train=False)
-            self._heads, self._targets = out["start"], out["target"]
-            self.solved_boards = out.get("solved_grid")
-        elif board_name == "offline_uniform":
-            st = ops.uniform_generate(keys, grid_size, num_agents)
-            self._heads, self._targets, self.solved_boards = st["start"], st["target"], None
-        elif board_name == "offline_parallel_rw":
-            out = ops.prw_generate(keys, grid_size, num_agents, split_first=False,
-                                   want_solved=True, want_train=False)
-            self._heads, self._targets = out["start"], out["target"]
-            self.solved_boards = out["solved_grid"]
-        else:
-            # the reference's else-branch would run ParallelRandomWalk for ANY other string; a
-            # typo silently changing the generator is not worth mirroring
-            raise ValueError(f"unknown board_name {board_name!r}")
+            return out["start"], out["target"], out.get("solved_grid")
+        if self.board_name == "offline_uniform":
+            st = ops.uniform_generate(keys, m, N)
+            return st["start"], st["target"], None
+        out = ops.prw_generate(keys, m, N, split_first=False, want_solved=True, want_train=False)
+        return out["start"], out["target"], out["solved_grid"]
+
+    def generate_n_boards(self, key: torch.Tensor, n_boards: int = 10,
+                          generate_solved_boards: bool = False):
+        """dataset_generator_jax.py:65-110 -- (heads, targets, solved_boards) of the boards
+        generated from split(key, n_boards): heads / targets of shape (n_boards, 2, N) (row and
+        column arrays per board, what `jnp.array` makes of the reference's lists), solved_boards
+        (n_boards, m, m) -- or [] where the reference returns an empty list (seed extension
+        without generate_solved_boards; the uniform generator has no solved board).  One batched
+        launch instead of the reference's loop of one jitted call per board.  Where the
+        reference's seed-extension branch returns None for heads and targets when it generates
+        solved boards (:84-95), this returns them as well: the same launch produces them."""
+        key = torch.as_tensor(key)
+        if key.shape != (2,):
+            raise ValueError("generate_n_boards expects one PRNG key (shape (2,))")
+        key = key.to(self._heads.device)  # (the dataset's device)
+        n = int(n_boards)
+        keys = split(key, n)
+        heads, targets, solved = self._generate(keys, generate_solved_boards)
+        return (heads.transpose(-1, -2), targets.transpose(-1, -2),
+                solved if solved is not None else [])
 
     @property
     def heads(self) -> torch.Tensor:

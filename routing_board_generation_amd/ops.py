@@ -76,10 +76,16 @@ class GeneratorSpec:
         return self._keepalive[0].device if self._keepalive[0] is not None else None
 
 
-def _gen_ref(gen: Optional["GeneratorSpec"]):
-    """Pointer argument for the *_gen entry points (None = ParallelRandomWalk)."""
+def _gen_ref(gen: Optional["GeneratorSpec"], device=None):
+    """Pointer argument for the *_gen entry points (None = ParallelRandomWalk).  `device` = the
+    device of the batch the launch works on: a generator that points to device memory (the
+    offline dataset's heads / targets) must live there -- the kernels dereference its raw
+    pointers, and a dataset built on another rank's GPU would fault or read through peer access."""
     if gen is None or gen.kind == nat.GEN_PARALLEL_RW:
         return None
+    if device is not None and gen.device is not None and gen.device != torch.device(device):
+        raise ValueError(f"the generator's dataset lives on {gen.device}, the env batch on "
+                         f"{torch.device(device)}: build the dataset generator with device=...")
     return C.byref(gen.struct)
 
 
@@ -464,7 +470,7 @@ def connector_reset(keys: torch.Tensor, m: int, N: int, state: Optional[StateBuf
     st = state if state is not None else alloc_state(B, m, N, dev)
     ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
     s, t = _state_struct(st, B, m, N), _timestep_struct(ts, B, m, N)
-    nat.check(nat.lib().rbg_connector_reset_gen(_gen_ref(gen), keys.data_ptr(), B, m, N,
+    nat.check(nat.lib().rbg_connector_reset_gen(_gen_ref(gen, dev), keys.data_ptr(), B, m, N,
                                                 C.byref(s), C.byref(t), None, 0, 0, _stream(dev)),
               "rbg_connector_reset")
     return st, ts
@@ -498,7 +504,7 @@ def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
     t = _timestep_struct(ts, B, m, N)
     p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward),
                       int(bool(auto_reset)))
-    nat.check(nat.lib().rbg_connector_step_gen(_gen_ref(gen), B, m, N, C.byref(si), C.byref(s_o),
+    nat.check(nat.lib().rbg_connector_step_gen(_gen_ref(gen, dev), B, m, N, C.byref(si), C.byref(s_o),
                                                action.data_ptr(), None, 0, C.byref(p),
                                                C.byref(t), None, 0, 0, _stream(dev)),
               "rbg_connector_step")
@@ -559,7 +565,7 @@ def connector_reset_prefetch(keys: torch.Tensor, m: int, N: int, stash: dict, ti
     ts = timestep if timestep is not None else alloc_timestep(B, m, N, dev)
     s, t, h = _state_struct(st, B, m, N), _timestep_struct(ts, B, m, N), _stash_struct(stash, B, m, N)
     nat.check(nat.lib().rbg_connector_reset_gen(
-        _gen_ref(gen), keys.data_ptr(), B, m, N, C.byref(s), C.byref(t), C.byref(h), int(tick),
+        _gen_ref(gen, dev), keys.data_ptr(), B, m, N, C.byref(s), C.byref(t), C.byref(h), int(tick),
         int(ready_delay), _stream(dev)), "rbg_connector_reset_prefetch")
     return st, ts
 
@@ -581,7 +587,7 @@ def connector_step_prefetch(state: StateBufs, action: torch.Tensor, stash: dict,
     t, h = _timestep_struct(ts, B, m, N), _stash_struct(stash, B, m, N)
     p = nat.EnvParams(int(time_limit), float(timestep_reward), float(connected_reward), 1)
     nat.check(nat.lib().rbg_connector_step_gen(
-        _gen_ref(gen), B, m, N, C.byref(si), C.byref(s_o), action.data_ptr(), None, 0, C.byref(p),
+        _gen_ref(gen, dev), B, m, N, C.byref(si), C.byref(s_o), action.data_ptr(), None, 0, C.byref(p),
         C.byref(t), C.byref(h), int(tick), int(ready_delay), _stream(dev)),
         "rbg_connector_step_prefetch")
     return so, ts
@@ -592,7 +598,7 @@ def stash_refill(stash: dict, m: int, gen: Optional[GeneratorSpec] = None) -> No
     B, N = stash["hits"].shape[0], stash["next"]["start"].shape[1]
     dev = stash["tag"].device
     h = _stash_struct(stash, B, m, N)
-    nat.check(nat.lib().rbg_stash_refill_gen(_gen_ref(gen), B, m, N, C.byref(h), _stream(dev)),
+    nat.check(nat.lib().rbg_stash_refill_gen(_gen_ref(gen, dev), B, m, N, C.byref(h), _stream(dev)),
               "rbg_stash_refill")
 
 
@@ -636,7 +642,7 @@ def connector_rollout(state: StateBufs, policy_keys: torch.Tensor, t0: int, n_st
             raise ValueError("epochs was built for another batch / grid / agent count")
         epochs.before_launch()
     rc = nat.lib().rbg_connector_rollout_gen(
-        _gen_ref(gen), B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(),
+        _gen_ref(gen, dev), B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(),
         int(t0) & 0xFFFFFFFF, int(n_steps), C.byref(p), C.byref(sp),
         C.byref(tp) if tp is not None else None, None, None,
         C.byref(epochs.struct) if use_stash else None, epochs.tick if use_stash else 0,
@@ -699,7 +705,7 @@ def connector_rollout_record(state: StateBufs, policy_keys: torch.Tensor, t0: in
             raise ValueError("epochs was built for another batch / grid / agent count")
         epochs.before_launch()
     rc = nat.lib().rbg_connector_rollout_gen(
-        _gen_ref(gen), B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(),
+        _gen_ref(gen, dev), B, m, N, C.byref(si), C.byref(s_o), policy_keys.data_ptr(),
         int(t0) & 0xFFFFFFFF, T,
         C.byref(p), C.byref(sp), None, C.byref(tp), _ptr(action),
         C.byref(epochs.struct) if use_stash else None, epochs.tick if use_stash else 0,

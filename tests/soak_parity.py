@@ -28,15 +28,24 @@ sys.path.insert(0, HERE)
 from helpers import assert_dicts_equal, state_to_np, timestep_to_np, to_np  # noqa: E402
 
 
+ALL_KINDS = "prw,uniform,seq_rw,seed_ext,philox,dataset,env,rollout"
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="")
-    ap.add_argument("--kinds", default="prw,uniform,seq_rw,seed_ext,philox,dataset,env,rollout")
+    ap.add_argument("--kinds", default=ALL_KINDS)
     ap.add_argument("--max-boards", type=int, default=6000, help="largest generator batch")
     args = ap.parse_args()
+    summary, failures = run(args)
+    return 1 if failures else 0
 
+
+def run(args, quiet: bool = False):
+    """The soak itself: `args` carries minutes, seed, out, kinds, max_boards (the command line's,
+    or tests/test_gpu_soak_slice.py's bounded slice).  Returns (summary dict, failed case lines)."""
     import torch
 
     import routing_board_generation_amd as rbg
@@ -276,13 +285,14 @@ def main() -> int:
                   flush=True)
     summary = {"summary": True, "soak_seed": args.seed, "minutes": args.minutes, "cases": n_cases,
                "failures": len(failures), "totals": totals}
-    print(json.dumps(summary), flush=True)
-    for f in failures[:20]:
-        print(json.dumps(f), flush=True)
+    if not quiet:
+        print(json.dumps(summary), flush=True)
+        for f in failures[:20]:
+            print(json.dumps(f), flush=True)
     if out:
         out.write(json.dumps(summary) + "\n")
         out.close()
-    return 1 if failures else 0
+    return summary, failures
 
 
 if __name__ == "__main__":

@@ -32,6 +32,13 @@ def test_bench_gpus_2_launches_itself():
     assert abs(line["launch_ms_over_ranks"]["max"] - 0.04) < 1e-12
     coll = line["collective"]
     assert coll["backend"] == "gloo" and coll["world_size"] == 2 and coll["all_reduce_us"] > 0
+    # the two other readings of N > 1: BASELINE configs[3] (4096 keys per rank of the 4096 N-key
+    # batch) and the strong reading (the global batch of 4096 cut into N shards)
+    c4, strong = line["c4"], line["strong"]
+    assert c4["global_batch"] == 8192 and c4["boards_per_gpu"] == 4096 and c4["scaling"] == "weak"
+    assert c4["boards"] == 2 * 4096 * 3
+    assert strong["global_batch"] == 4096 and strong["boards_per_gpu"] == 2048
+    assert strong["boards"] == 4096 * 3 and strong["scaling"] == "strong"
 
 
 def test_bench_relays_the_childs_exit_code():

@@ -521,6 +521,39 @@ def test_board_dataset_generator(rbg, oracle):
     assert (to_np(state.grid) == est["grid"][:8]).all() and ts.observation.grid.shape == (8, N, m, m)
 
 
+def test_dataset_generate_n_boards(rbg, oracle):
+    """BoardDatasetGeneratorJAX.generate_n_boards(key, n_boards, generate_solved_boards)
+    (dataset_generator_jax.py:65-110) for a key other than PRNGKey(0): (heads, targets,
+    solved_boards) of split(key, n) in the reference's (n, 2, N) layout, from one batched launch;
+    the constructor's dataset is the same call on PRNGKey(0)."""
+    m, N, n = 10, 5, 37
+    key = rbg.PRNGKey(1234)
+    ekeys = oracle.split(oracle.prng_key(1234), n)
+    prw = rbg.BoardDatasetGeneratorJAX(m, N, board_name="offline_parallel_rw", number_of_boards=8)
+    heads, targets, solved = prw.generate_n_boards(key, n)
+    eh, et, es, _ = oracle.generate_board_batch(ekeys, m, N, threads=8)
+    assert heads.shape == (n, 2, N) and targets.shape == (n, 2, N)
+    assert (to_np(heads) == eh.transpose(0, 2, 1)).all()
+    assert (to_np(targets) == et.transpose(0, 2, 1)).all()
+    assert (to_np(solved) == es).all()
+    assert len(prw) == 8 and prw.generate_n_boards(key)[0].shape == (10, 2, N)  # default n_boards
+    d0 = prw.generate_n_boards(rbg.PRNGKey(0), 8)
+    assert (to_np(d0[0]) == to_np(prw.heads)).all() and (to_np(d0[2]) == to_np(prw.solved_boards)).all()
+    # the reference's default board_name with the config's keywords (connector.yaml:10-15)
+    se = rbg.BoardDatasetGeneratorJAX(m, N, randomness=0.0, two_sided=True, extension_iterations=1,
+                                      extension_steps=1e23, number_of_boards=4)
+    heads, targets, solved = se.generate_n_boards(key, n)
+    est = oracle.seed_extension_batch(ekeys, m, N, split_first=False, threads=8)[0]
+    assert solved == []  # (:96-104: no solved boards unless asked for)
+    assert (to_np(heads) == est["start"].transpose(0, 2, 1)).all()
+    assert (to_np(targets) == est["target"].transpose(0, 2, 1)).all()
+    _, _, solved = se.generate_n_boards(key, n, generate_solved_boards=True)
+    esolved = oracle.seed_extension_batch(ekeys, m, N, split_first=False, threads=8)[1]
+    assert (to_np(solved) == esolved).all()
+    with pytest.raises(ValueError):
+        se.generate_n_boards(rbg.split(key, 3), 4)  # one key, not a batch
+
+
 # ------------------------------------------------------------------------------ SequentialRandomWalk
 def test_sequential_random_walk_golden(rbg, goldens):
     """profiling_generators.ipynb cell 7 (G7): SequentialRandomWalkGenerator(10, 5)(PRNGKey(0))."""
@@ -896,6 +929,14 @@ def test_bench_gpus_2_launches_itself_on_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 10 and line["value"] > 0
     assert line["config"]["global_batch"] == 8192 and line["scaling"] == "weak"
+    # BASELINE configs[3] and the strong reading ride on the same line (bench.py: generator_block)
+    c4, strong = line["c4"], line["strong"]
+    assert (c4["grid_size"], c4["num_agents"], c4["global_batch"], c4["boards_per_gpu"]) == \
+        (32, 20, 8192, 4096) and c4["value"] > 0 and c4["scaling"] == "weak"
+    assert (strong["grid_size"], strong["num_agents"], strong["global_batch"],
+            strong["boards_per_gpu"]) == (16, 10, 4096, 2048)
+    assert strong["value"] > 0 and strong["scaling"] == "strong"
+    assert c4["launch_ms_over_ranks"]["max"] >= c4["launch_ms_over_ranks"]["min"] > 0
 
 
 @pytest.mark.parametrize("prefetch", [False, True])

@@ -48,7 +48,7 @@ def test_struct_layouts_match_header(native, tmp_path):
     structs = {"rbg_state": native.State, "rbg_timestep": native.Timestep,
                "rbg_env_params": native.EnvParams, "rbg_stash": native.Stash,
                "rbg_rollout_stats": native.RolloutStats, "rbg_generator": native.Generator,
-               "rbg_step_call": native.StepCall}
+               "rbg_step_call": native.StepCall, "rbg_stash_roll_call": native.StashRollCall}
     lines = []
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -82,7 +82,7 @@ def test_argument_errors_do_not_need_a_gpu(native):
 
 
 def test_argument_errors_of_the_generator_and_stash_entry_points(native):
-    """The ABI 8 entry points (rbg_generator, rbg_step_call, rolling refills) check their
+    """The ABI 8 / 9 entry points (rbg_generator, rbg_step_call, rolling refills) check their
     arguments before any launch: no GPU needed, nothing is dereferenced on the device."""
     nat = native
     lib = nat.lib()
@@ -119,9 +119,33 @@ def test_argument_errors_of_the_generator_and_stash_entry_points(native):
     deep = nat.Stash(state, one, one, one, None, None, None, None, None, 13)
     assert lib.rbg_stash_refill_gen(None, 8, 16, 10, C.byref(deep), None) == -3
     assert b"depth" in lib.rbg_last_error()
-    assert lib.rbg_stash_list(8, 16, 10, C.byref(stash), None) == -1          # no scratch area
+    assert lib.rbg_stash_list(8, 16, 10, C.byref(stash), 1, 1, None) == -1    # no scratch area
     assert lib.rbg_stash_refill_listed(None, 8, 16, 10, C.byref(stash), None) == -1
     assert b"scratch" in lib.rbg_last_error()
+    # ABI 9: a list with in-flight claims needs its two ready ticks; one call per epoch boundary
+    claims = nat.Stash(state, one, one, one, None, None, one, one, None, 2)
+    assert lib.rbg_stash_list(8, 16, 10, C.byref(claims), 0, 5, None) == -3
+    assert lib.rbg_stash_list(8, 16, 10, C.byref(claims), 9, 5, None) == -3
+    assert b"claim_ready" in lib.rbg_last_error()
+    assert lib.rbg_stash_roll(None) == -1 and b"NULL call" in lib.rbg_last_error()
+    roll = nat.StashRollCall()
+    roll.B, roll.m, roll.N = 8, 16, 10
+    assert lib.rbg_stash_roll(C.byref(roll)) == -1 and b"NULL stash" in lib.rbg_last_error()
+    roll.stash = C.pointer(stash)
+    roll.launched = roll.listed = roll.done = one
+    assert lib.rbg_stash_roll(C.byref(roll)) == -1 and b"in-flight" in lib.rbg_last_error()
+    roll.stash = C.pointer(claims)
+    roll.miss_word = one
+    assert lib.rbg_stash_roll(C.byref(roll)) == -1 and b"miss snapshot" in lib.rbg_last_error()
+    # ticks are int32: a launch whose tick + ready_delay would wrap is refused, never truncated
+    call.state_in = call.state_out = state
+    call.timestep = nat.Timestep(*[one] * 9, None, None)
+    call.action = one
+    call.stash = C.pointer(stash)
+    for tick, delay in ((-1, 1), (5, -1), (2 ** 31 - 1, 1), (2 ** 30, 2 ** 30)):
+        call.tick, call.ready_delay = tick, delay
+        assert lib.rbg_connector_step_call(C.byref(call)) == -3, (tick, delay)
+        assert b"rebase" in lib.rbg_last_error()
     # a rollout launch handles two slots per env
     three = nat.Stash(state, one, one, one, None, None, None, None, None, 3)
     params = nat.EnvParams(50, -0.03, 0.1, 1)

@@ -114,3 +114,88 @@ def test_a_lagging_counter_is_neither_a_storm_nor_calm():
     assert s.K == 16
     s.observe_misses(*w.observe(MissWatch.pack(12 * 200 + 100 * 40, 244)))  # four calm refills
     assert s.K == 32
+
+
+def test_rebase_renumbers_the_serial_schedule_without_moving_anything():
+    """Ticks are int32 in the ABI (include/rbg_prw.h): a session that would outlive 2^31 launches
+    subtracts an offset from its tick, its next refill's tick and every ready_at it handed out.
+    A schedule that rebases every few hundred launches announces, relative to the current tick,
+    exactly what its twin that never rebases does; near 2^30 the numbers stay in int32."""
+    for K, adaptive in ((1, False), (16, False), (48, True)):
+        a, b = RefillSchedule(K, 4096, adaptive), RefillSchedule(K, 4096, adaptive)
+        shifted = 0
+        for step in range(5000):
+            if step % 777 == 776:
+                off = b.tick - 1
+                b.rebase(off)
+                shifted += off
+            assert (a.ready_delay(), a.refill_due()) == (b.ready_delay(), b.refill_due())
+            assert a.tick == b.tick + shifted and b.tick <= 777 + 1
+            for s in (a, b):
+                if s.refill_due():
+                    s.observe_misses(500 if step % 900 < 300 else 0)
+                    s.refill_queued()
+                s.launched()
+    s = RefillSchedule(20)
+    s.tick, s.refill_after = (1 << 30) + 7, (1 << 30) + 13
+    s.rebase(s.tick - 1)
+    assert (s.tick, s.refill_after, s.ready_delay()) == (1, 7, 7)
+    try:
+        s.rebase(5)  # beyond the current tick
+        assert False
+    except ValueError:
+        pass
+
+
+def test_rolling_epochs_across_a_rebase():
+    """The rolling form's arithmetic (schedule.RollingEpochs): requests of epoch e are usable from
+    the first tick of epoch e + lead, ring slots follow the epoch, and a rebase -- a multiple of
+    K x ring launches -- changes neither the phase within the epoch, nor any ring slot, nor any
+    tick difference.  ready_at values on the device move down by the same offset (modelled here
+    by the list `handed`)."""
+    from routing_board_generation_amd.schedule import RollingEpochs
+
+    for K, lead in ((1, 2), (8, 2), (32, 3), (64, 6)):
+        sa, sb = RefillSchedule(K), RefillSchedule(K)
+        ra, rb = RollingEpochs(sa, lead), RollingEpochs(sb, lead)
+        assert ra.ring == lead + 1
+        handed, shifted = [], 0  # absolute ready_at values the rebasing twin gave to the device
+        threshold = 5 * K * ra.ring + 3
+        for step in range(40 * K * ra.ring):
+            if sb.tick >= threshold:
+                off = rb.rebase_offset()
+                assert off > 0 and off % (K * rb.ring) == 0
+                sb.rebase(off)
+                handed = [max(0, h - off) for h in handed]
+                shifted += off
+            assert sa.tick == sb.tick + shifted and sb.tick < threshold + 2 * K * rb.ring
+            assert ra.ready_delay() == rb.ready_delay() >= 1
+            assert ra.at_boundary() == rb.at_boundary()
+            handed.append(sb.tick + rb.ready_delay())
+            if sb.tick > 0:
+                # usable exactly at the first tick of epoch e + lead
+                e = rb.epoch()
+                assert sb.tick + rb.ready_delay() == 1 + K * (e + lead)
+            if ra.at_boundary():
+                slot_a, claim_a, skip_a, aw_a, prev_a = ra.boundary()
+                slot_b, claim_b, skip_b, aw_b, prev_b = rb.boundary()
+                assert (slot_a, aw_a, prev_a) == (slot_b, aw_b, prev_b)
+                assert claim_a == claim_b + shifted and skip_b == claim_b + K
+                assert claim_b == sb.tick + rb.ready_delay()  # what this epoch's requests carry
+                # the refill awaited before the next launch is the one whose rows become usable
+                # there: refill e' = e + 1 - lead serves ready_at = 1 + K (e' + lead) = next tick
+                if aw_b is not None:
+                    assert 1 + K * ((rb.epoch() + 1 - lead) + lead) == sb.tick + 1
+            sa.launched()
+            sb.launched()
+        assert shifted > 0
+        # nothing handed out lies in the future beyond lead epochs, nothing is negative
+        assert all(0 <= h <= sb.tick + K * (lead + 1) for h in handed)
+    # at the real threshold the numbers stay far inside int32
+    s = RefillSchedule(64)
+    r = RollingEpochs(s, 3)
+    s.tick = (1 << 30) + 12345
+    before = (s.tick - 1) % 64, ((s.tick - 1) // 64) % r.ring
+    s.refill_after = s.tick + 5
+    s.rebase(r.rebase_offset())
+    assert s.tick <= 2 * 64 * r.ring and ((s.tick - 1) % 64, ((s.tick - 1) // 64) % r.ring) == before
