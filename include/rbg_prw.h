@@ -511,10 +511,12 @@ int rbg_stash_refill_listed(const rbg_generator *generator, int B, int m, int N,
  *   (claim_ready, skip_ready), the miss snapshot (optional, below), record `listed`,
  *   rbg_stash_refill_listed, record `done`.
  * All events are hipEvent_t owned by the caller.  Miss snapshot (miss_word non-NULL): the list
- * launch also sums stash->misses into *miss_acc (device, zero before the first call; cleared by
- * the call), one more tiny launch writes (sum << 20 | stamp & 0xFFFFF) to *miss_word (device) and
- * 8 bytes are copied to *miss_host (pinned host memory) on gen_stream -- never a synchronisation;
- * the host reads whatever has arrived (schedule.MissWatch). */
+ * launch also sums stash->misses through *miss_acc (a device work word, zero before the first
+ * call and again after every call) and writes (sum << 20 | stamp & 0xFFFFF) to *miss_word
+ * (device) and to *miss_host (pinned host memory: written by the launch itself when the device
+ * can address it -- hipHostMalloc / hipHostRegister memory -- else by an 8-byte copy on
+ * gen_stream) -- never a synchronisation; the host reads whatever has arrived
+ * (schedule.MissWatch). */
 typedef struct rbg_stash_roll_call {
   const rbg_generator *generator; /* NULL = ParallelRandomWalk */
   int32_t B, m, N;

@@ -50,9 +50,10 @@ class VmapAutoResetWrapper(_Wrapper):
         generator for all the envs that restarted since the last one, instead of every step launch
         waiting for the generator runs of its own finished envs; results are identical with and
         without it.  prefetch_delay=None takes the generator's measured best
-        (ops.GeneratorSpec.refill: 20 steps for ParallelRandomWalk, 48 with two slots per env for
-        SequentialRandomWalk / SeedExtension, none for Uniform and the offline dataset, whose
-        "generation" is cheaper than a stash row copy).
+        (ops.GeneratorSpec.refill: 20 steps in line for ParallelRandomWalk; refills rolling beside
+        the stepping stream for SequentialRandomWalk / SeedExtension -- every 32 / 64 steps with
+        8 / 10 slots per env, shortened to fit the time limit; none for Uniform and the offline
+        dataset, whose "generation" is cheaper than a stash row copy).  It was 16 until round 2.
         donate=True/False overrides the env's setting (Connector(donate=...))."""
         super().__init__(env)
         env.unwrapped._configure(auto_reset=True,

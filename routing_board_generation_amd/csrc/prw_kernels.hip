@@ -547,7 +547,8 @@ int rbg_stash_refill(int B, int m, int N, const rbg_stash *stash, void *stream) 
 // packing); 1: list only; 2: generate the listed rows
 static int stash_refill_impl(const rbg_generator *generator, int B, int m, int N,
                              const rbg_stash *stash, void *stream, int mode, int claim_ready = 1,
-                             int skip_ready = 0, unsigned long long *miss_acc = nullptr) {
+                             int skip_ready = 0, const rbg_stash_roll_call *snap = nullptr,
+                             void *snap_host = nullptr) {
   if (B < 0) return fail(RBG_E_SHAPE, "rbg_stash_refill: B < 0");
   RefillArgs a;
   memset(&a, 0, sizeof(a));
@@ -599,7 +600,13 @@ static int stash_refill_impl(const rbg_generator *generator, int B, int m, int N
   a.envs = B;
   a.claim_ready = claim_ready;
   a.skip_ready = skip_ready;
-  a.miss_acc = mode == 1 ? miss_acc : nullptr;
+  // (the list launch's miss snapshot counts its waves in 20 bits of the work word)
+  if (mode == 1 && snap && ((long long)a.B + 255) / 256 * 4 < (1ll << 20)) {
+    a.miss_acc = (unsigned long long *)snap->miss_acc;
+    a.miss_word = (unsigned long long *)snap->miss_word;
+    a.miss_host = (unsigned long long *)snap_host;
+    a.stamp = snap->stamp;
+  }
   const int envs_per_block = wpb * (kWaveSize / lpb);
   dim3 grid((a.B + envs_per_block - 1) / envs_per_block), block(kWaveSize * wpb);
   hipStream_t st = (hipStream_t)stream;
@@ -683,18 +690,30 @@ int rbg_stash_roll(const rbg_stash_roll_call *c) {
   if (int rc = check_hip(hipStreamWaitEvent(gen, (hipEvent_t)c->launched, 0), who)) return rc;
   if (c->after_listed)
     if (int rc = check_hip(hipStreamWaitEvent(gen, (hipEvent_t)c->after_listed, 0), who)) return rc;
+  // The snapshot goes straight into the host's pinned word when the device can address it
+  // (mapped host memory: hipHostMalloc / hipHostRegister, what torch's pin_memory() gives);
+  // otherwise 8 bytes are copied behind the list launch.
+  void *host_dev = nullptr;
+  if (c->miss_word) {
+    static thread_local const void *seen_host = nullptr;
+    static thread_local void *seen_dev = nullptr;
+    if (seen_host != c->miss_host) {
+      void *d = nullptr;
+      if (hipHostGetDevicePointer(&d, c->miss_host, 0) != hipSuccess) {
+        (void)hipGetLastError();  // not mapped: the copy below
+        d = nullptr;
+      }
+      seen_host = c->miss_host;
+      seen_dev = d;
+    }
+    host_dev = seen_dev;
+  }
   if (int rc = stash_refill_impl(nullptr, c->B, c->m, c->N, c->stash, gen, 1, c->claim_ready,
-                                 c->skip_ready,
-                                 c->miss_word ? (unsigned long long *)c->miss_acc : nullptr))
+                                 c->skip_ready, c->miss_word ? c : nullptr, host_dev))
     return rc;
-  if (c->miss_word && c->B > 0) {
-    hipLaunchKernelGGL(stash_miss_pack_kernel, dim3(1), dim3(1), 0, gen,
-                       (unsigned long long *)c->miss_acc, (unsigned long long *)c->miss_word,
-                       c->stamp);
-    if (int rc = check_hip(hipGetLastError(), who)) return rc;
+  if (c->miss_word && !host_dev && c->B > 0)
     if (int rc = check_hip(hipMemcpyAsync(c->miss_host, c->miss_word, sizeof(int64_t),
                                           hipMemcpyDeviceToHost, gen), who)) return rc;
-  }
   if (int rc = check_hip(hipEventRecord((hipEvent_t)c->listed, gen), who)) return rc;
   if (int rc = stash_refill_impl(c->generator, c->B, c->m, c->N, c->stash, gen, 2)) return rc;
   return check_hip(hipEventRecord((hipEvent_t)c->done, gen), who);

@@ -44,7 +44,30 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 #endif
   const int lane = threadIdx.x & (kWaveSize - 1);
   const SubWave<64> sw(lane);
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (MODE == kModeStep && DEEP) {
+#if defined(RBG_PROBE_SETPRIO_FIRST)  // developer probe: round 3's form (see below)
+    if (a.stash.inflight) __builtin_amdgcn_s_setprio(1);
+#elif !defined(RBG_PROBE_SETPRIO_LATE)
+    // Rolling refills (refills run beside the step launches): the step's waves outrank the
+    // refill's in issue arbitration, from their first instruction on.  A refill wave is the
+    // oldest wave on its SIMD for a millisecond and wins every cycle it is ready in; at equal
+    // priority a SeedExtension refill makes the step launches it overlaps 3-7x longer (13 ->
+    // 30-105 us), at priority 1 they take 17-18 us and the refill, which has slack, takes the
+    // rest.
+    // Written as an asm WITHOUT side effects whose (zero) result feeds the env index: to the
+    // compiler the s_setprio builtin is a call with unmodelled side effects, and a wave-uniform
+    // global load that follows one is no longer provably unclobbered -- it becomes a vector load
+    // + s_waitcnt + v_readfirstlane instead of an s_load.  Round 3 had the builtin first thing,
+    // and State.step_count (needed for a branch) then cost every wave of the launch an exposed
+    // memory round trip before its grid load was even issued (12.1 -> 12.3-13.3
+    // us per launch).  The data dependence keeps the instruction ahead of everything indexed by
+    // the env; harmless for a deep stash that is refilled in line.
+    int zero;
+    asm("s_setprio 1\n\ts_mov_b32 %0, 0" : "=s"(zero));
+    wib += zero;
+#endif
+  }
   // (the other generators' kernels may run fewer waves per workgroup: SeedExtension's LDS area
   // at large grids -- launch_env)
   const int wpb = KIND == kGenPrw ? kEnvWavesPerBlock : (int)(blockDim.x >> 6);
@@ -96,19 +119,11 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
     act = a.action[(size_t)b * N + lane];
   }
   const StashProbe probe = stash_probe_issue<DEEP>(a.stash, a.B, b, lane);  // in flight during the step
-  // Rolling refills (stash.inflight given: refills run beside the step launches): the step's
-  // waves outrank the refill's in issue arbitration.  A refill wave is the oldest wave on its
-  // SIMD for a millisecond and wins every cycle it is ready in; at equal priority a SeedExtension
-  // refill makes the step launches it overlaps 3-7x longer (13 -> 30-105 us), at priority 1 they
-  // take 17-18 us and the refill, which has slack, takes the rest.
-  // NOT at the kernel's entry: s_setprio has unmodelled side effects for the compiler, and a
-  // wave-uniform global load that follows one is no longer provably unclobbered -- it becomes a
-  // vector load + s_waitcnt + v_readfirstlane instead of an s_load.  Round 3 had it first thing,
-  // and State.step_count (needed for a branch) then cost every wave of the launch an exposed
-  // memory round trip before its grid load was even issued (12.1 -> 12.6-13.3 us).
+#if defined(RBG_PROBE_SETPRIO_LATE)  // developer probe: the priority raised only after the loads
   if constexpr (DEEP) {
     if (a.stash.inflight) __builtin_amdgcn_s_setprio(1);
   }
+#endif
   RowPrefetch pf;
   pf.row = -1;
   if (a.p.auto_reset && a.stash.tag && step_count + 1 >= a.p.time_limit && (g.m & 3) == 0 &&
@@ -216,7 +231,11 @@ struct RefillArgs {
   int claim_ready;  // ready_at of the requests this list serves (>= 1): the value a claim carries
   int skip_ready;   // ready_at of the requests the NEXT list will serve
   int envs;         // B (a.B counts rows = depth * B here)
-  unsigned long long *miss_acc;  // nullable: += sum of stash.misses (rbg_stash_roll's snapshot)
+  // rbg_stash_roll's miss snapshot, taken by the list launch itself (all nullable together)
+  unsigned long long *miss_acc;   // work word, zero between launches
+  unsigned long long *miss_word;  // device copy of the snapshot
+  unsigned long long *miss_host;  // the same word in mapped host memory (NULL: the caller copies)
+  uint32_t stamp;
 };
 
 template <int LPB>
@@ -237,7 +256,9 @@ __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
   split2_lanes(sw, key, rk, unused);  // VmapAutoResetWrapper: key, _ = split(state.key)
   const Key2 next_key = regenerate(sw, board, W, g, a.N, rk, ag);
   store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
-  __threadfence();  // the tag publishes a complete row (release; consumers are ordered by the host)
+  // (no fence between the row and its tag: whoever consumes the row is ordered behind this whole
+  // launch by the host -- ready_at -- never by the tag alone; an agent-scope fence here is an L2
+  // write-back per wavefront and took the refill of 4096 rows from 34 to 86 us)
   if (sw.l == 0) *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
 }
 
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void stash_refill_kernel(RefillArgs a) {
 // wavefronts: scratch[0] = their number (zeroed by the host before), scratch[1..] = the rows, in
 // no particular order (which rows share a wavefront does not matter to any result).
 // With in-flight claims (stash.inflight: refills overlap each other and the step launches):
-//   * the claim is read FIRST, with acquire semantics -- the producer publishes tag -> fence ->
+//   * the claim is read FIRST, the tag after it -- the producer publishes tag -> fence ->
 //     inflight = 0 (release), so a row seen released is seen with the tag its producer wrote, and
 //     nothing is listed (generated) twice;
 //   * a claim carries the ready tick of the requests its list served (claim_ready).  A row that is
@@ -264,10 +285,27 @@ __global__ void stash_list_kernel(RefillArgs a) {
   bool need = false;
   if (r < a.B) {
     int claim = 0;
-    if (a.stash.inflight)
+    uint2 have;
+    if (a.stash.inflight) {
+#if defined(RBG_PROBE_LIST_ACQUIRE)  // developer probe: the textbook form (an L2 invalidate per wave)
       claim = __hip_atomic_load(&a.stash.inflight[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)r]);
+#else
+      // claim, then tag, both read at agent scope (past any line this XCD's L2 may hold) with the
+      // first complete before the second is issued: a released row is seen with the tag its
+      // producer published before the release -- without the cache-wide invalidate an
+      // agent-scope acquire costs every wave of this launch while step launches run beside it
+      claim = __hip_atomic_load(&a.stash.inflight[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const unsigned long long t = __hip_atomic_load(
+          reinterpret_cast<const unsigned long long *>(&a.stash.tag[2 * (size_t)r]),
+          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      have = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
+#endif
+    } else {
+      have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)r]);
+    }
     const uint2 want = *reinterpret_cast<const uint2 *>(&a.stash.refill_key[2 * (size_t)r]);
-    const uint2 have = *reinterpret_cast<const uint2 *>(&a.stash.tag[2 * (size_t)r]);
     need = want.x != have.x || want.y != have.y;
     if (need && a.stash.inflight) {
       if (claim != 0) {  // an earlier, still running refill is generating the row: leave it alone
@@ -279,10 +317,26 @@ __global__ void stash_list_kernel(RefillArgs a) {
       }
     }
   }
-  if (a.miss_acc) {  // rbg_stash_roll: the stash's miss counter summed on the way (one atomic per wave)
+  if (a.miss_acc) {
+    // rbg_stash_roll's snapshot of the stash's miss counter, on the way: every wave adds
+    // (its sum << 20) + 1 to ONE word with ONE atomic -- sum and ticket in the same word, so
+    // the wave that draws the last ticket holds the complete sum without any fence -- and that
+    // wave publishes (sum << 20 | stamp) for the host and clears the word for the next launch.
+    // (A launch of its own for this, or a device-to-host copy, sat on the generator stream in
+    // front of every producer: +0.5 / +0.8 us per step for SeedExtension.)
     unsigned long long v = r < a.envs && a.stash.misses ? (unsigned long long)a.stash.misses[r] : 0ull;
     for (int off = kWaveSize / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((threadIdx.x & (kWaveSize - 1)) == 0 && v != 0ull) atomicAdd(a.miss_acc, v);
+    if ((threadIdx.x & (kWaveSize - 1)) == 0) {
+      const unsigned long long waves = (unsigned long long)gridDim.x * (blockDim.x / kWaveSize);
+      const unsigned long long add = (v << 20) + 1ull;
+      const unsigned long long old = atomicAdd(a.miss_acc, add);
+      if ((old & 0xFFFFFull) + 1ull == waves) {
+        const unsigned long long w = (((old + add) >> 20) << 20) | (unsigned long long)(a.stamp & 0xFFFFFu);
+        *a.miss_word = w;
+        if (a.miss_host) __hip_atomic_store(a.miss_host, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        atomicExch(a.miss_acc, 0ull);
+      }
+    }
   }
   const uint64_t m = __ballot(need);
   if (m == 0ull) return;
@@ -291,13 +345,6 @@ __global__ void stash_list_kernel(RefillArgs a) {
   if (lane == 0) base = atomicAdd(&a.stash.scratch[0], __popcll(m));
   base = __builtin_amdgcn_readfirstlane(base);
   if (need) a.stash.scratch[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = r;
-}
-
-// (misses << 20 | stamp) as ONE 8-byte word for the host (schedule.MissWatch), accumulator cleared
-__global__ void stash_miss_pack_kernel(unsigned long long *acc, unsigned long long *word,
-                                       uint32_t stamp) {
-  *word = (*acc << 20) | (unsigned long long)(stamp & 0xFFFFFu);
-  *acc = 0ull;
 }
 
 template <int LPB, int KIND>
@@ -341,7 +388,9 @@ __global__ __launch_bounds__(kBlock) void stash_refill_gen_kernel(RefillArgs a) 
       const Key2 next_key = regenerate_kind<LPB, KIND>(sw, board, W, g, a.N, rk, ag, a.gen);
       if (need) {
         store_state(sw, board, g, a.N, b, ag, 0, next_key, a.stash.next);
-        __threadfence();  // the tag publishes a complete row
+#if defined(RBG_PROBE_FENCE_BEFORE_TAG)  // developer probe: what a fence between row and tag costs
+        __threadfence();
+#endif
         if (sw.l == 0) {
           *reinterpret_cast<uint2 *>(&a.stash.tag[2 * (size_t)b]) = want;
           if (a.listed && a.stash.inflight)  // release: whoever sees the row released sees its tag

@@ -29,7 +29,13 @@ def main():
     ap.add_argument("--chunks", type=int, default=1, help="time the window in this many pieces")
     ap.add_argument("--flags", default="", help="extra hipcc flags: time a variant build of the "
                                                 "library (built here, into gpurun_out/)")
+    ap.add_argument("--no-miss-snapshot", action="store_true",
+                    help="rolling refills without the per-epoch miss counter snapshot")
     args = ap.parse_args()
+    if args.no_miss_snapshot:
+        from routing_board_generation_amd import session
+
+        session.EpochStash.SNAPSHOT_MISSES = False
     if args.flags:
         from routing_board_generation_amd import _native as nat
 
