@@ -273,9 +273,15 @@ def test_adaptive_refill_period_follows_short_episodes(rbg, oracle):
         assert_dicts_equal(timestep_to_np(ts), ets, f"step {t} timestep.")
         periods.append(sess.epochs.K)
     assert sess.epochs.fell_back and sess.epochs.serial and sess.epochs.adaptive
-    # (eight slots per env cover 32 steps of 4-step episodes: the period halves until the misses
-    # per refill stop, which they do at 16)
-    assert min(periods) <= 16, periods[::20]
+    # The designed end point is 16, not lower: eight slots per env ask 8 x 4 = 32 steps ahead, and
+    # in line a request is served at most K steps later, so the misses per refill stop as soon as
+    # K <= 16 and the rule (halve WHILE misses keep arriving, schedule.RefillSchedule) has no reason
+    # to go further.  Whether a run also visits 8 depends on when the asynchronous miss snapshots
+    # land -- one more halving happens if a storm's last snapshot arrives after K reached 16 (round
+    # 3's first version of this test saw 8 on one box and was written as <= 6, which no rule
+    # promises) -- so 16 is asserted, together with the rule's floor (K0 / 8 = 4 after the
+    # fallback's K0 = 32).
+    assert 4 <= min(periods) <= 16, periods[::20]
     misses = int(to_np(sess.epochs.stash["misses"]).sum())
     hits = int(to_np(sess.epochs.stash["hits"]).sum())
     assert misses > 0 and hits > misses, (hits, misses)
