@@ -1,5 +1,6 @@
 # rocprofv3 passes behind profiles/rN_* (run on the GPU box through gpurun, in two calls:
 #   bash tools/collect_profiles.sh a [tag]   default run (+ SQ issue counters) and the step population
+#   bash tools/collect_profiles.sh s [tag]   the step population alone
 #   bash tools/collect_profiles.sh b [tag]   stream (65 536 and 262 144 envs), record, --all-configs
 # then `python tools/summarize_profile.py <tag> "" _step _stream _stream262k _record` here;
 # tag defaults to r4).
@@ -20,6 +21,8 @@ if [ "$1" = "a" ]; then
   run "" --cpu-sample 0
   timeout -k 10 250 $P --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace -d gpurun_out/prof_${T}_issue -o x -- python3 bench.py --mode generator --cpu-sample 0 > /dev/null 2> gpurun_out/prof_${T}_issue.err
   echo "issue done"
+  run _step --mode step-replay
+elif [ "$1" = "s" ]; then  # the step population alone
   run _step --mode step-replay
 else
   run _stream --mode stream
