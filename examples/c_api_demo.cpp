@@ -2,7 +2,8 @@
 // links librbg_prw.so (include/rbg_prw.h) and the HIP runtime, generates the BASELINE configs[1]
 // batch (16x16 grid, 10 agents, 4096 boards from split(PRNGKey(0), 4096)), resets a Connector
 // env on it and runs a 50-step fused random rollout; then steps the same env coupled to another
-// generator (SequentialRandomWalk) through rbg_generator / rbg_step_call / rbg_stash_refill_gen.
+// generator (SequentialRandomWalk) through rbg_generator / rbg_step_call / rbg_stash_refill_gen,
+// and once more with that generator's refills rolling beside the stepping stream (rbg_stash_roll).
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include examples/c_api_demo.cpp \
 //         -L routing_board_generation_amd/lib -lrbg_prw -Wl,-rpath,'$ORIGIN' -o c_api_demo
@@ -155,5 +156,90 @@ int main(int argc, char **argv) {
   }
   printf("seq_rw env after 20 steps: grid_fnv1a %016llx  stash hits %lld  misses %lld\n",
          (unsigned long long)fnv, hits, misses);
+
+  // The same env once more with its refills ROLLING beside the stepping stream (what
+  // VmapAutoResetWrapper does by default for this generator): four slots per env, a refill
+  // behind every epoch of K = 4 launches on one of two generator streams, usable `lead` = 2
+  // epochs later; ONE rbg_stash_roll call per epoch boundary (events of this program), 40 steps.
+  {
+    const int D4 = 4, Kr = 4, lead = 2, ring = lead + 1, R = D4 * B;
+    hipStream_t gstream[2];
+    HIP_OK(hipStreamCreate(&gstream[0]));
+    HIP_OK(hipStreamCreate(&gstream[1]));
+    hipEvent_t launched[3], listed[3], done[3];
+    for (int i = 0; i < ring; ++i) {
+      HIP_OK(hipEventCreateWithFlags(&launched[i], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&listed[i], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    rbg_stash rs = {};
+    rs.next = {dalloc<int32_t>((size_t)R * m * m), dalloc<int32_t>(R),
+               dalloc<int32_t>((size_t)R * N * 2), dalloc<int32_t>((size_t)R * N * 2),
+               dalloc<int32_t>((size_t)R * N * 2), dalloc<uint32_t>((size_t)R * 2)};
+    rs.tag = dalloc<uint32_t>((size_t)R * 2);
+    rs.ready_at = dalloc<int32_t>(R);
+    rs.refill_key = dalloc<uint32_t>((size_t)R * 2);
+    rs.hits = dalloc<int32_t>(B);
+    rs.misses = dalloc<int32_t>(B);
+    rs.inflight = dalloc<int32_t>(R);              // claims of the refills in flight
+    rs.far_key = dalloc<uint32_t>((size_t)B * 2);  // one new request per restart that hit
+    rs.depth = D4;
+    HIP_OK(hipMemsetAsync(rs.tag, 0, (size_t)R * 8, stream));
+    HIP_OK(hipMemsetAsync(rs.ready_at, 0, (size_t)R * 4, stream));
+    HIP_OK(hipMemsetAsync(rs.refill_key, 0, (size_t)R * 8, stream));
+    HIP_OK(hipMemsetAsync(rs.hits, 0, (size_t)B * 4, stream));
+    HIP_OK(hipMemsetAsync(rs.misses, 0, (size_t)B * 4, stream));
+    HIP_OK(hipMemsetAsync(rs.inflight, 0, (size_t)R * 4, stream));
+    HIP_OK(hipMemsetAsync(rs.far_key, 0, (size_t)B * 8, stream));
+    rbg_stash per_refill[3];  // every refill in flight lists its rows into a scratch area of its own
+    for (int i = 0; i < ring; ++i) {
+      per_refill[i] = rs;
+      per_refill[i].scratch = dalloc<int32_t>((size_t)R + 1);
+    }
+    rs.scratch = per_refill[0].scratch;
+    // tick 0: the reset; its requests are served by one refill on the stepping stream (tick 1 on)
+    RBG_OK(rbg_connector_reset_gen(&gen, keys, B, m, N, &st, &ts, &rs, 0, 1, stream));
+    RBG_OK(rbg_stash_refill_gen(&gen, B, m, N, &rs, stream));
+    call.stash = &rs;
+    call.state_in = call.state_out = st;
+    for (int t = 1; t <= 40; ++t) {  // epoch e covers the ticks 1 + e Kr .. (e + 1) Kr
+      const int e = (t - 1) / Kr;
+      call.tick = t;
+      call.ready_delay = 1 + Kr * (e + lead) - t;  // usable from the first tick of epoch e + lead
+      RBG_OK(rbg_connector_step_call(&call));
+      if ((t - 1) % Kr == Kr - 1) {
+        rbg_stash_roll_call roll = {};
+        roll.generator = &gen;
+        roll.B = B; roll.m = m; roll.N = N;
+        roll.claim_ready = 1 + Kr * (e + lead);
+        roll.skip_ready = roll.claim_ready + Kr;
+        roll.stash = &per_refill[e % ring];
+        roll.step_stream = stream;
+        roll.gen_stream = gstream[e % 2];
+        roll.launched = launched[e % ring];
+        roll.listed = listed[e % ring];
+        roll.done = done[e % ring];
+        roll.await_done = e + 1 >= lead ? done[(e + 1 - lead) % ring] : nullptr;
+        roll.after_listed = e > 0 ? listed[(e - 1) % ring] : nullptr;
+        RBG_OK(rbg_stash_roll(&roll));
+      }
+    }
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(h_grid.data(), st.grid, h_grid.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(h_hits.data(), rs.hits, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(h_miss.data(), rs.misses, (size_t)B * 4, hipMemcpyDeviceToHost));
+    fnv = 1469598103934665603ull;
+    for (int32_t v : h_grid) {
+      fnv ^= (uint32_t)v;
+      fnv *= 1099511628211ull;
+    }
+    hits = misses = 0;
+    for (int b = 0; b < B; ++b) {
+      hits += h_hits[b];
+      misses += h_miss[b];
+    }
+    printf("seq_rw env, rolling refills, after 40 steps: rolling_fnv1a %016llx  rolling hits %lld  "
+           "rolling misses %lld\n", (unsigned long long)fnv, hits, misses);
+  }
   return 0;
 }

@@ -746,8 +746,27 @@ def test_c_api_demo_program(oracle, tmp_path):
     for v in st["grid"].astype(np.uint32).ravel().tolist():
         fnv = ((fnv ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert f"grid_fnv1a {fnv:016x}" in out, out
-    hits, misses = (int(x) for x in out.split("stash hits ")[1].replace("misses", "").split())
+    hits, misses = (int(x) for x in
+                    out.split("stash hits ")[1].splitlines()[0].replace("misses", "").split())
     assert hits + misses == 3000 and hits >= 2000, out
+    # the third part: the same env from a fresh reset with ROLLING refills driven from C++ (one
+    # rbg_stash_roll per epoch, hipEvents of the program): 40 NOOP steps -> six restarts per env
+    st, _, _ = oracle.seq_rw_generator_batch(keys, 16, 10, threads=8)
+    for _ in range(40):
+        ts = oracle.connector_step_batch(st, noop, time_limit=6, auto_reset=False, threads=8)
+        idx = np.nonzero(ts["step_type"] == 2)[0]
+        if idx.size:
+            fresh, _, _ = oracle.seq_rw_generator_batch(
+                np.stack([oracle.split(k)[0] for k in st["key"][idx]]), 16, 10, threads=8)
+            for f in st:
+                st[f][idx] = fresh[f]
+    fnv = 1469598103934665603
+    for v in st["grid"].astype(np.uint32).ravel().tolist():
+        fnv = ((fnv ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert f"rolling_fnv1a {fnv:016x}" in out, out
+    rhits = int(out.split("rolling hits ")[1].split()[0])
+    rmiss = int(out.split("rolling misses ")[1].split()[0])
+    assert rhits + rmiss == 6000 and rhits >= 4000, out
 
 
 # ------------------------------------------------------------------------------ prefetched resets

@@ -194,6 +194,13 @@ def test_listed_producer_generates_each_row_once_and_releases_it(rbg, oracle):
     nat.check(lib.rbg_stash_roll(C.byref(call)), "rbg_stash_roll")
     torch.cuda.synchronize()
     assert int(stash["scratch"][0]) == 0 and MissWatch().observe(int(host[0]))[1] == 78
+    # host memory the device cannot address (pageable): the snapshot arrives by an 8-byte copy
+    pageable = torch.zeros((1,), dtype=torch.int64)
+    call.miss_host, call.stamp = pageable.data_ptr(), 79
+    nat.check(lib.rbg_stash_roll(C.byref(call)), "rbg_stash_roll")
+    torch.cuda.synchronize()
+    assert MissWatch().observe(int(pageable[0])) == (B * (B - 1) // 2, 79)
+    assert int(word[0]) == int(pageable[0])
 
 
 @pytest.mark.parametrize("name,delay", [("online_parallel_rw", None), ("online_seq_rw", None),
