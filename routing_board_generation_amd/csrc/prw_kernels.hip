@@ -418,7 +418,12 @@ static int launch_env(EnvArgs &a, void *stream, const char *what) {
   } else if (deep_stash(a.stash)) {
     hipLaunchKernelGGL(connector_step_deep_kernel, grid, block, lds, st, a);
   } else {
+#if defined(RBG_PROBE_PRELOAD)
+    hipLaunchKernelGGL(connector_step_kernel, grid, block, lds, st, a.in.grid, a.in.step_count,
+                       a.in.start, a.in.target, a.in.position, a.in.key, a.B, a.N, a);
+#else
     hipLaunchKernelGGL(connector_step_kernel, grid, block, lds, st, a);
+#endif
   }
   return check_hip(hipGetLastError(), what);
 }

@@ -37,8 +37,12 @@ enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
 // DEEP (step only): the stash has several slots per env or in-flight claims (rolling refills);
 // false = no stash or a plain one, and the step carries nothing of the deep form -- its
 // probes, its request rule, its wave priority cost the plain form 0.5-1 us per launch in round 3.
+// `in`, `B`, `N`: a.in / a.B / a.N, handed over separately so that a kernel whose signature leads
+// with them gets them PRELOADED into SGPRs at wave launch (-amdgpu-kernarg-preload-count: the
+// first loads of a wave then do not wait for an s_load of the kernarg segment).
 template <int MODE, int KIND, bool DEEP = true>
-__device__ __forceinline__ void connector_body(const EnvArgs &a) {
+__device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs &in, const int B,
+                                               const int N_) {
 #if defined(RBG_PROBE_STEP_TIMES)  // developer probe (tools/probe_step.py --times)
   const uint32_t probe_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
 #endif
@@ -72,11 +76,11 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
   // at large grids -- launch_env)
   const int wpb = KIND == kGenPrw ? kEnvWavesPerBlock : (int)(blockDim.x >> 6);
   const int b = blockIdx.x * wpb + wib;
-  if (b >= a.B) return;
+  if (b >= B) return;
   uint32_t *board = g_lds + wib * env_slab_words<64>(a.g, a.gen);
   uint32_t *W = board + board_words(a.g);
   const Geo g = a.g;
-  const int N = a.N;
+  const int N = N_;
   AgentRegs ag = {0, 0, 0, 0, 0, 0};
 
   if constexpr (MODE == kModeReset) {  // ---- Connector.reset ----------------------------------
@@ -85,7 +89,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
     kin.b = a.keys[2 * (size_t)b + 1];
     const Key2 key = regenerate_kind<64, KIND>(sw, board, W, g, N, kin, ag, a.gen);
     store_state(sw, board, g, N, b, ag, 0, key, a.out);
-    request_refill<KIND>(sw, a.stash, a.B, b, key, a.tick + a.ready_delay);
+    request_refill<KIND>(sw, a.stash, B, b, key, a.tick + a.ready_delay);
     write_observation(sw, board, g, N, b, ag, 0, a.ts,
                       lane < N ? action_mask_bits(board, g, ag, lane) : 1u);
     write_extras(sw, board, g, N, b, ag, a.ts);
@@ -95,7 +99,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 
   int step_count;
   Key2 key;
-  load_state(sw, board, g, N, b, a.in, ag, step_count, key);
+  load_state(sw, board, g, N, b, in, ag, step_count, key);
 
   if constexpr (MODE == kModeObserve) {  // ---- observe an existing state (restart timestep) ---
     write_observation(sw, board, g, N, b, ag, step_count, a.ts,
@@ -118,7 +122,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
   } else if (lane < N) {
     act = a.action[(size_t)b * N + lane];
   }
-  const StashProbe probe = stash_probe_issue<DEEP>(a.stash, a.B, b, lane);  // in flight during the step
+  const StashProbe probe = stash_probe_issue<DEEP>(a.stash, B, b, lane);  // in flight during the step
 #if defined(RBG_PROBE_SETPRIO_LATE)  // developer probe: the priority raised only after the loads
   if constexpr (DEEP) {
     if (a.stash.inflight) __builtin_amdgcn_s_setprio(1);
@@ -174,7 +178,7 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
       key = regenerate_kind<64, KIND>(sw, board, W, g, N, rk, ag, a.gen);
     }
     step_count = 0;
-    request_refill<KIND, DEEP ? kMaxStashDepth : 1>(sw, a.stash, a.B, b, key,
+    request_refill<KIND, DEEP ? kMaxStashDepth : 1>(sw, a.stash, B, b, key,
                                                     a.tick + a.ready_delay, row, true, probe.far);
     const uint32_t bits = lane < N ? action_mask_bits(board, g, ag, lane) : 1u;
     store_state(sw, board, g, N, b, ag, step_count, key, a.out);
@@ -193,28 +197,37 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a) {
 }
 
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_kernel(EnvArgs a) {
-  connector_body<kModeReset, kGenPrw>(a);
+  connector_body<kModeReset, kGenPrw>(a, a.in, a.B, a.N);
 }
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_observe_kernel(EnvArgs a) {
-  connector_body<kModeObserve, kGenPrw>(a);
+  connector_body<kModeObserve, kGenPrw>(a, a.in, a.B, a.N);
 }
+#if defined(RBG_PROBE_PRELOAD)  // developer probe: the State pointers as leading (preloaded) arguments
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_kernel(
+    int32_t *grid, int32_t *step_count, int32_t *start, int32_t *target, int32_t *position,
+    uint32_t *key, int B, int N, EnvArgs a) {
+  const StatePtrs in = {grid, step_count, start, target, position, key};
+  connector_body<kModeStep, kGenPrw, false>(a, in, B, N);
+}
+#else
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_kernel(EnvArgs a) {
-  connector_body<kModeStep, kGenPrw, false>(a);
+  connector_body<kModeStep, kGenPrw, false>(a, a.in, a.B, a.N);
 }
+#endif
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_deep_kernel(
     EnvArgs a) {
-  connector_body<kModeStep, kGenPrw, true>(a);
+  connector_body<kModeStep, kGenPrw, true>(a, a.in, a.B, a.N);
 }
 // Connector(generator = Uniform / SequentialRandomWalk / SeedExtension / offline dataset)
 template <int KIND>
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_gen_kernel(
     EnvArgs a) {
-  connector_body<kModeReset, KIND>(a);
+  connector_body<kModeReset, KIND>(a, a.in, a.B, a.N);
 }
 template <int KIND, bool DEEP>
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_gen_kernel(
     EnvArgs a) {
-  connector_body<kModeStep, KIND, DEEP>(a);
+  connector_body<kModeStep, KIND, DEEP>(a, a.in, a.B, a.N);
 }
 
 
