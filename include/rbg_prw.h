@@ -228,7 +228,10 @@ int rbg_connector_step(int B, int m, int N, const rbg_state *state_in, const rbg
  *   RBG_E_PARAM.  A session that outlives 2^31 launches rebases: between two launches, with no
  *   refill in flight, subtract one offset from its tick and from every ready_at (clamped at 0) --
  *   routing_board_generation_amd.session.EpochStash does at tick 2^30.)
- *   depth       slots per env, 1 .. 12; slot s of env b is row s * B + b of every array below
+ *   depth       slots per env, 1 .. 12; slot s of env b is row b * depth + s of every array below
+ *               (ABI 9; the slots of an env are adjacent so that an env's probes touch one or two
+ *               cache lines per array; ABI 7-8 had row s * B + b.  Only the env side of the
+ *               library maps (env, slot) to rows: refills work on rows)
  *   next        a full rbg_state of depth * B rows: next[r] = reset(split(tag[r])[0])
  *   tag         uint32 [depth*B][2]: the State.key next[r] was generated for (zero-initialised)
  *   ready_at    int32 [depth*B]: first launch tick that may consume the row (zero-initialised)

@@ -514,7 +514,7 @@ def connector_step(state: StateBufs, action: torch.Tensor, time_limit: int = 50,
 # ------------------------------------------------------------------------------------- prefetch
 def alloc_stash(B: int, m: int, N: int, device, depth: int = 1, rolling: bool = False) -> dict:
     """Buffers of include/rbg_prw.h::rbg_stash (tag / ready_at / refill_key / hits zeroed);
-    `depth` slots per env, slot s of env b in row s * B + b.  rolling: also the in-flight marks
+    `depth` slots per env, slot s of env b in row b * depth + s.  rolling: also the in-flight marks
     of refills that overlap each other and the step launches (EpochStash(serial=False))."""
     if depth not in range(1, 13):
         raise ValueError("stash depth must be in [1, 12]")
