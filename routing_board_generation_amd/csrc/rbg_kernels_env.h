@@ -97,6 +97,19 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs
     return;
   }
 
+  // Policy fused into the step launch: the random word of (step, agent) does not depend on the
+  // state, so its key is fetched first and its Threefry runs while the grid is still in flight
+  // (only the pick among the legal actions needs the mask of the state just loaded).
+  uint32_t policy_y0 = 0u;
+  if constexpr (MODE == kModeStep) {
+#if !defined(RBG_PROBE_POLICY_LATE)
+    if (a.policy_keys) {
+      uint32_t y1;
+      threefry(a.policy_keys[2 * (size_t)b], a.policy_keys[2 * (size_t)b + 1], a.policy_t,
+               (uint32_t)lane, policy_y0, y1);
+    }
+#endif
+  }
   int step_count;
   Key2 key;
   load_state(sw, board, g, N, b, in, ag, step_count, key);
@@ -112,13 +125,17 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs
   // ---- Connector.step --------------------------------------------------------------------------
   int act = 0;
   if (a.policy_keys) {
-    // policy fused into the step launch: the mask rbg_random_actions would read from the previous
-    // timestep is the mask of the state just loaded
+    // the mask rbg_random_actions would read from the previous timestep is the mask of the state
+    // just loaded
+#if defined(RBG_PROBE_POLICY_LATE)  // developer probe: the policy's Threefry behind the state load
     Key2 pk;
     pk.a = a.policy_keys[2 * (size_t)b];
     pk.b = a.policy_keys[2 * (size_t)b + 1];
     if (lane < N)
       act = random_policy_action(pk, a.policy_t, (uint32_t)lane, action_mask_bits(board, g, ag, lane));
+#else
+    if (lane < N) act = policy_pick(policy_y0, action_mask_bits(board, g, ag, lane));
+#endif
   } else if (lane < N) {
     act = a.action[(size_t)b * N + lane];
   }
