@@ -110,6 +110,16 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs
     }
 #endif
   }
+  // ... and so are the caller's actions and the stash probe: both are issued ahead of the state
+  // load instead of behind its wait
+  int act_early = 0;
+  StashProbe probe = {make_uint2(0u, 0u), 0x7FFFFFFF, make_uint2(0u, 0u)};
+  if constexpr (MODE == kModeStep) {
+#if !defined(RBG_PROBE_ACTION_LATE)
+    if (!a.policy_keys && lane < N) act_early = a.action[(size_t)b * N + lane];
+    probe = stash_probe_issue<DEEP>(a.stash, B, b, lane);
+#endif
+  }
   int step_count;
   Key2 key;
   load_state(sw, board, g, N, b, in, ag, step_count, key);
@@ -137,9 +147,15 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs
     if (lane < N) act = policy_pick(policy_y0, action_mask_bits(board, g, ag, lane));
 #endif
   } else if (lane < N) {
+#if defined(RBG_PROBE_ACTION_LATE)  // developer probe: action and stash probe behind the state load
     act = a.action[(size_t)b * N + lane];
+#else
+    act = act_early;
+#endif
   }
-  const StashProbe probe = stash_probe_issue<DEEP>(a.stash, B, b, lane);  // in flight during the step
+#if defined(RBG_PROBE_ACTION_LATE)
+  probe = stash_probe_issue<DEEP>(a.stash, B, b, lane);  // in flight during the step
+#endif
 #if defined(RBG_PROBE_SETPRIO_LATE)  // developer probe: the priority raised only after the loads
   if constexpr (DEEP) {
     if (a.stash.inflight) __builtin_amdgcn_s_setprio(1);
