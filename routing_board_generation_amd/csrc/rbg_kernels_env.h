@@ -40,7 +40,12 @@ enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
 // `in`, `B`, `N`: a.in / a.B / a.N, handed over separately so that a kernel whose signature leads
 // with them gets them PRELOADED into SGPRs at wave launch (-amdgpu-kernarg-preload-count: the
 // first loads of a wave then do not wait for an s_load of the kernarg segment).
-template <int MODE, int KIND, bool DEEP = true>
+// POLICY (step only): the action comes from the masked-uniform random policy inside the launch
+// (a.policy_keys) instead of a.action.  A template parameter, not a test of the pointer: the
+// kernel of the caller's own actions then carries no early read of that kernarg word and none
+// of the policy's code (as a run-time branch at the head of one kernel it cost the path without
+// a fused policy 0.3 us per launch).
+template <int MODE, int KIND, bool DEEP = true, bool POLICY = false>
 __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs &in, const int B,
                                                const int N_) {
 #if defined(RBG_PROBE_STEP_TIMES)  // developer probe (tools/probe_step.py --times)
@@ -101,24 +106,10 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs
   // state, so its key is fetched first and its Threefry runs while the grid is still in flight
   // (only the pick among the legal actions needs the mask of the state just loaded).
   uint32_t policy_y0 = 0u;
-  if constexpr (MODE == kModeStep) {
-#if !defined(RBG_PROBE_POLICY_LATE)
-    if (a.policy_keys) {
-      uint32_t y1;
-      threefry(a.policy_keys[2 * (size_t)b], a.policy_keys[2 * (size_t)b + 1], a.policy_t,
-               (uint32_t)lane, policy_y0, y1);
-    }
-#endif
-  }
-  // ... and so are the caller's actions and the stash probe: both are issued ahead of the state
-  // load instead of behind its wait
-  int act_early = 0;
-  StashProbe probe = {make_uint2(0u, 0u), 0x7FFFFFFF, make_uint2(0u, 0u)};
-  if constexpr (MODE == kModeStep) {
-#if !defined(RBG_PROBE_ACTION_LATE)
-    if (!a.policy_keys && lane < N) act_early = a.action[(size_t)b * N + lane];
-    probe = stash_probe_issue<DEEP>(a.stash, B, b, lane);
-#endif
+  if constexpr (MODE == kModeStep && POLICY) {
+    uint32_t y1;
+    threefry(a.policy_keys[2 * (size_t)b], a.policy_keys[2 * (size_t)b + 1], a.policy_t,
+             (uint32_t)lane, policy_y0, y1);
   }
   int step_count;
   Key2 key;
@@ -134,33 +125,14 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs
 
   // ---- Connector.step --------------------------------------------------------------------------
   int act = 0;
-  if (a.policy_keys) {
+  if constexpr (POLICY) {
     // the mask rbg_random_actions would read from the previous timestep is the mask of the state
     // just loaded
-#if defined(RBG_PROBE_POLICY_LATE)  // developer probe: the policy's Threefry behind the state load
-    Key2 pk;
-    pk.a = a.policy_keys[2 * (size_t)b];
-    pk.b = a.policy_keys[2 * (size_t)b + 1];
-    if (lane < N)
-      act = random_policy_action(pk, a.policy_t, (uint32_t)lane, action_mask_bits(board, g, ag, lane));
-#else
     if (lane < N) act = policy_pick(policy_y0, action_mask_bits(board, g, ag, lane));
-#endif
   } else if (lane < N) {
-#if defined(RBG_PROBE_ACTION_LATE)  // developer probe: action and stash probe behind the state load
     act = a.action[(size_t)b * N + lane];
-#else
-    act = act_early;
-#endif
   }
-#if defined(RBG_PROBE_ACTION_LATE)
-  probe = stash_probe_issue<DEEP>(a.stash, B, b, lane);  // in flight during the step
-#endif
-#if defined(RBG_PROBE_SETPRIO_LATE)  // developer probe: the priority raised only after the loads
-  if constexpr (DEEP) {
-    if (a.stash.inflight) __builtin_amdgcn_s_setprio(1);
-  }
-#endif
+  const StashProbe probe = stash_probe_issue<DEEP>(a.stash, B, b, lane);  // in flight during the step
   RowPrefetch pf;
   pf.row = -1;
   if (a.p.auto_reset && a.stash.tag && step_count + 1 >= a.p.time_limit && (g.m & 3) == 0 &&
@@ -251,16 +223,25 @@ __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_
     EnvArgs a) {
   connector_body<kModeStep, kGenPrw, true>(a, a.in, a.B, a.N);
 }
+// ... with the random policy inside the launch (rbg_connector_step_gen with policy_keys)
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_policy_kernel(
+    EnvArgs a) {
+  connector_body<kModeStep, kGenPrw, false, true>(a, a.in, a.B, a.N);
+}
+__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_deep_policy_kernel(
+    EnvArgs a) {
+  connector_body<kModeStep, kGenPrw, true, true>(a, a.in, a.B, a.N);
+}
 // Connector(generator = Uniform / SequentialRandomWalk / SeedExtension / offline dataset)
 template <int KIND>
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_gen_kernel(
     EnvArgs a) {
   connector_body<kModeReset, KIND>(a, a.in, a.B, a.N);
 }
-template <int KIND, bool DEEP>
+template <int KIND, bool DEEP, bool POLICY>
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_gen_kernel(
     EnvArgs a) {
-  connector_body<kModeStep, KIND, DEEP>(a, a.in, a.B, a.N);
+  connector_body<kModeStep, KIND, DEEP, POLICY>(a, a.in, a.B, a.N);
 }
 
 

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=1, help="time the window in this many pieces")
     ap.add_argument("--flags", default="", help="extra hipcc flags: time a variant build of the "
                                                 "library (built here, into gpurun_out/)")
+    ap.add_argument("--lib", default="", help="time a prebuilt library of the same ABI instead "
+                                              "of the tree's (tools/build_ab_libs.sh)")
     ap.add_argument("--no-miss-snapshot", action="store_true",
                     help="rolling refills without the per-epoch miss counter snapshot")
     args = ap.parse_args()
@@ -36,6 +38,10 @@ def main():
         from routing_board_generation_amd import session
 
         session.EpochStash.SNAPSHOT_MISSES = False
+    if args.lib:
+        from routing_board_generation_amd import _native as nat
+
+        nat.LIB_PATH = os.path.abspath(args.lib)  # before anything loads the library
     if args.flags:
         from routing_board_generation_amd import _native as nat
 
