@@ -27,8 +27,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernels that read their state with global_load_dwordx4 streams (grids, 16 B per lane)
-WIDE_READS = ("connector_step_kernel", "connector_observe_kernel", "connector_rollout_kernel",
-              "connector_step_gen_kernel", "connector_rollout_gen_kernel")
+WIDE_READS = ("connector_step_kernel", "connector_step_policy_kernel", "connector_step_deep_kernel",
+              "connector_step_deep_policy_kernel", "connector_observe_kernel",
+              "connector_rollout_kernel", "connector_step_gen_kernel", "connector_rollout_gen_kernel")
 
 
 def per_kernel(path, counter):
