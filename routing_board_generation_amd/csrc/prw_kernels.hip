@@ -178,15 +178,14 @@ void launch_env_gen(const EnvArgs &a, dim3 grid, dim3 block, size_t lds, hipStre
   if (a.mode == kModeReset) {
     hipLaunchKernelGGL(connector_reset_gen_kernel<KIND>, grid, block, lds, st, a);
   } else if (deep_stash(a.stash)) {
-    if (a.policy_keys) {
-      hipLaunchKernelGGL((connector_step_gen_kernel<KIND, true, true>), grid, block, lds, st, a);
-    } else {
-      hipLaunchKernelGGL((connector_step_gen_kernel<KIND, true, false>), grid, block, lds, st, a);
-    }
+    hipLaunchKernelGGL((connector_step_gen_kernel<KIND, true, kPolicyAtRunTime>), grid, block, lds,
+                       st, a);
   } else if (a.policy_keys) {
-    hipLaunchKernelGGL((connector_step_gen_kernel<KIND, false, true>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((connector_step_gen_kernel<KIND, false, kPolicyInLaunch>), grid, block, lds,
+                       st, a);
   } else {
-    hipLaunchKernelGGL((connector_step_gen_kernel<KIND, false, false>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((connector_step_gen_kernel<KIND, false, kActionsFromCaller>), grid, block,
+                       lds, st, a);
   }
 }
 
@@ -422,11 +421,7 @@ static int launch_env(EnvArgs &a, void *stream, const char *what) {
   } else if (a.mode == kModeReset) {
     hipLaunchKernelGGL(connector_reset_kernel, grid, block, lds, st, a);
   } else if (deep_stash(a.stash)) {
-    if (a.policy_keys) {
-      hipLaunchKernelGGL(connector_step_deep_policy_kernel, grid, block, lds, st, a);
-    } else {
-      hipLaunchKernelGGL(connector_step_deep_kernel, grid, block, lds, st, a);
-    }
+    hipLaunchKernelGGL(connector_step_deep_kernel, grid, block, lds, st, a);
   } else if (a.policy_keys) {
     hipLaunchKernelGGL(connector_step_policy_kernel, grid, block, lds, st, a);
   } else {

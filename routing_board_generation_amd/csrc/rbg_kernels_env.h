@@ -40,12 +40,17 @@ enum { kModeReset = 0, kModeObserve = 1, kModeStep = 2 };
 // `in`, `B`, `N`: a.in / a.B / a.N, handed over separately so that a kernel whose signature leads
 // with them gets them PRELOADED into SGPRs at wave launch (-amdgpu-kernarg-preload-count: the
 // first loads of a wave then do not wait for an s_load of the kernarg segment).
-// POLICY (step only): the action comes from the masked-uniform random policy inside the launch
-// (a.policy_keys) instead of a.action.  A template parameter, not a test of the pointer: the
-// kernel of the caller's own actions then carries no early read of that kernarg word and none
-// of the policy's code (as a run-time branch at the head of one kernel it cost the path without
-// a fused policy 0.3 us per launch).
-template <int MODE, int KIND, bool DEEP = true, bool POLICY = false>
+// POL (step only): where the action comes from -- the caller (a.action) or the masked-uniform
+// random policy inside the launch (a.policy_keys).  For the plain form a template parameter, not
+// a test of the pointer: the kernel of the caller's own actions then carries no early read of
+// that kernarg word and none of the policy's code (as a run-time branch at the head of one
+// kernel it cost the path without a fused policy 0.3 us per launch).
+// The deep form keeps the run-time test (kPolicyAtRunTime): beside rolling refills neither variant
+// of the compile-time form did better than it (SeedExtension 18.4-18.9 against 17.3-17.4 us per
+// step, SequentialRandomWalk 16.8-17.1 against 16.6 -- that generator's producers run at their
+// throughput limit, and any shift in the step's instruction schedule moves the balance).
+enum { kActionsFromCaller = 0, kPolicyInLaunch = 1, kPolicyAtRunTime = 2 };
+template <int MODE, int KIND, bool DEEP = true, int POL = kPolicyAtRunTime>
 __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs &in, const int B,
                                                const int N_) {
 #if defined(RBG_PROBE_STEP_TIMES)  // developer probe (tools/probe_step.py --times)
@@ -105,9 +110,14 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs
   // Policy fused into the step launch: the random word of (step, agent) does not depend on the
   // state, so its key is fetched first and its Threefry runs while the grid is still in flight
   // (only the pick among the legal actions needs the mask of the state just loaded).
+  // (Plain stash form only: beside rolling refills a step wave that spends 70 instructions
+  // before its loads go out gives the refill's waves that much more of a head start -- 17.1 /
+  // 18.6 against 16.6 / 17.4 us per step for the two rolling generators; the deep form keeps the
+  // evaluation behind the state load.)
+  constexpr bool kPolicyFirst = MODE == kModeStep && POL == kPolicyInLaunch;
   uint32_t policy_y0 = 0u;
   int b_state = b;  // (the env index the state is loaded with)
-  if constexpr (MODE == kModeStep && POLICY) {
+  if constexpr (kPolicyFirst) {
     uint32_t y1;
     threefry(a.policy_keys[2 * (size_t)b], a.policy_keys[2 * (size_t)b + 1], a.policy_t,
              (uint32_t)lane, policy_y0, y1);
@@ -134,9 +144,14 @@ __device__ __forceinline__ void connector_body(const EnvArgs &a, const StatePtrs
 
   // ---- Connector.step --------------------------------------------------------------------------
   int act = 0;
-  if constexpr (POLICY) {
+  if (POL == kPolicyInLaunch || (POL == kPolicyAtRunTime && a.policy_keys)) {
     // the mask rbg_random_actions would read from the previous timestep is the mask of the state
     // just loaded
+    if constexpr (!kPolicyFirst) {
+      uint32_t y1;
+      threefry(a.policy_keys[2 * (size_t)b], a.policy_keys[2 * (size_t)b + 1], a.policy_t,
+               (uint32_t)lane, policy_y0, y1);
+    }
     if (lane < N) act = policy_pick(policy_y0, action_mask_bits(board, g, ag, lane));
   } else if (lane < N) {
     act = a.action[(size_t)b * N + lane];
@@ -221,36 +236,34 @@ __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_
     int32_t *grid, int32_t *step_count, int32_t *start, int32_t *target, int32_t *position,
     uint32_t *key, int B, int N, EnvArgs a) {
   const StatePtrs in = {grid, step_count, start, target, position, key};
-  connector_body<kModeStep, kGenPrw, false>(a, in, B, N);
+  connector_body<kModeStep, kGenPrw, false, kActionsFromCaller>(a, in, B, N);
 }
 #else
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_kernel(EnvArgs a) {
-  connector_body<kModeStep, kGenPrw, false>(a, a.in, a.B, a.N);
+  connector_body<kModeStep, kGenPrw, false, kActionsFromCaller>(a, a.in, a.B, a.N);
 }
 #endif
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_deep_kernel(
     EnvArgs a) {
   connector_body<kModeStep, kGenPrw, true>(a, a.in, a.B, a.N);
 }
-// ... with the random policy inside the launch (rbg_connector_step_gen with policy_keys)
+// ... with the random policy inside the launch (rbg_connector_step_gen with policy_keys; plain
+// stash form -- the deep form decides at run time, connector_body)
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_policy_kernel(
     EnvArgs a) {
-  connector_body<kModeStep, kGenPrw, false, true>(a, a.in, a.B, a.N);
+  connector_body<kModeStep, kGenPrw, false, kPolicyInLaunch>(a, a.in, a.B, a.N);
 }
-__global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_deep_policy_kernel(
-    EnvArgs a) {
-  connector_body<kModeStep, kGenPrw, true, true>(a, a.in, a.B, a.N);
-}
+
 // Connector(generator = Uniform / SequentialRandomWalk / SeedExtension / offline dataset)
 template <int KIND>
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_reset_gen_kernel(
     EnvArgs a) {
   connector_body<kModeReset, KIND>(a, a.in, a.B, a.N);
 }
-template <int KIND, bool DEEP, bool POLICY>
+template <int KIND, bool DEEP, int POL>
 __global__ __launch_bounds__(kWaveSize * kEnvWavesPerBlock) void connector_step_gen_kernel(
     EnvArgs a) {
-  connector_body<kModeStep, KIND, DEEP, POLICY>(a, a.in, a.B, a.N);
+  connector_body<kModeStep, KIND, DEEP, POL>(a, a.in, a.B, a.N);
 }
 
 
