@@ -492,3 +492,43 @@ def test_long_runs_do_not_depend_on_the_stash_schedule(rbg, name, B, steps, tl):
     assert_dicts_equal(results[0][0], results[1][0], f"{name} final state.")
     assert (results[0][1] == results[1][1]).all() and results[0][2] == results[1][2]
     assert results[0][2] > (steps // (tl + 10)) * B
+
+
+@pytest.mark.parametrize("name", GENERATORS)
+def test_policy_inside_the_step_launch_for_every_generator(rbg, name):
+    """The masked-uniform random policy computed INSIDE the step launch (rbg_connector_step_gen with
+    policy_keys: its own kernel instantiation for the plain stash form, a run-time branch for the
+    deep one) gives exactly the trajectory of { rbg_random_actions; step with those actions } --
+    every generator, its default stash schedule, buffers compared after every step."""
+    import torch
+
+    from routing_board_generation_amd import ops
+    from routing_board_generation_amd.interface.board_generator_interface import make_online_generator
+
+    m, N, B, tl, steps = 16, 10, 192, 9, 45
+    kw = dict(randomness=0.0, two_sided=True, number_of_boards=40) if name.startswith("offline") else {}
+    gen = (rbg.ParallelRandomWalkPhiloxGenerator(m, N) if name == "parallel_rw_philox"
+           else make_online_generator(name, m, N, **kw)).native_spec()
+    sched = {"every": 16, "depth": 1, "serial": True, "lead": 2, "streams": 2, **gen.refill}
+    every = min(sched["every"], 6) if sched["every"] else 0  # (short episodes: refill often)
+    keys, pkeys = _keys(rbg, 33, B), _keys(rbg, 34, B)
+    loops = []
+    for fuse in (False, True):
+        st, ts = ops.alloc_state(B, m, N, "cuda"), ops.alloc_timestep(B, m, N, "cuda")
+        loop = ops.StepLoop(st, ts, pkeys, time_limit=tl, refill_every=every, fuse_policy=fuse,
+                            gen=gen, stash_depth=sched["depth"], serial_refill=sched["serial"],
+                            refill_lead=sched["lead"], refill_streams=sched["streams"])
+        loop.reset(keys)
+        loops.append((loop, st, ts))
+    for t in range(steps):
+        for loop, _, _ in loops:
+            loop.step(t)
+        (_, sa, ta), (_, sb, tb) = loops
+        for k in ("grid", "step_count", "start", "target", "position"):
+            assert torch.equal(sa[k], sb[k]), (name, t, k)
+        assert torch.equal(sa["key"].view(torch.int32), sb["key"].view(torch.int32)), (name, t)
+        for k in ("obs_grid", "action_mask", "reward", "discount", "step_type"):
+            assert torch.equal(ta[k], tb[k]), (name, t, k)
+    for loop, _, _ in loops:
+        loop.drain()
+    assert int((loops[0][2]["step_type"] == 2).sum()) >= 0
